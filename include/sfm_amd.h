@@ -1,0 +1,151 @@
+/* sfm_amd.h - C-ABI of libsfm_amd.so (MI355X / gfx950 hot path of Sovik-Ghosh/SFM).
+ *
+ * The reference has no FFI layer: its hot path is two Python methods,
+ *   ImageMatcher.match_features          /root/reference/utils/find_matches.py:141-155
+ *   StructureFromMotion.bundle_adjust    /root/reference/utils/sfm_reconstruction.py:401-549
+ * (plus compute_reconstruction_stats :582-631, a by-product of the residual kernel).
+ * This header is what a ctypes binding for those two methods binds instead of
+ * cv2.BFMatcher.knnMatch (find_matches.py:144-147) and scipy.optimize.least_squares
+ * (sfm_reconstruction.py:506-514).  INTEGRATION.md shows the reference-side stub.
+ *
+ * Conventions: every data pointer is a DEVICE pointer (HBM resident, caller-allocated,
+ * caller-owned) unless its name ends in _host.  All work is enqueued on the handle's
+ * HIP stream (sfm_set_stream; default = the null stream); functions return without
+ * synchronising unless stated.  Return value 0 = OK, <0 = error (sfm_last_error).
+ * One handle per (process, device); a handle is not thread-safe.
+ */
+#ifndef SFM_AMD_H
+#define SFM_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct sfm_ctx* sfm_handle;
+
+enum { SFM_OK = 0, SFM_ERR_ARG = -1, SFM_ERR_HIP = -2, SFM_ERR_WORKSPACE = -3, SFM_ERR_NUMERIC = -4 };
+
+int         sfm_create(int device, sfm_handle* out);
+void        sfm_destroy(sfm_handle h);
+const char* sfm_last_error(sfm_handle h);
+int         sfm_set_stream(sfm_handle h, void* hip_stream);
+int         sfm_synchronize(sfm_handle h);
+const char* sfm_version(void);
+
+/* ------------------------------------------------------------------ matcher
+ * Replaces cv2.BFMatcher(norm).knnMatch(desc1, desc2, k=2) + the ratio loop
+ * (find_matches.py:144-153).  Distances are float32 as OpenCV's DMatch.distance.
+ */
+enum {
+  SFM_METRIC_L2_U8   = 0,  /* uint8 [n,dim], dim % 32 == 0 (SIFT: 128): exact integer d^2 on i8 MFMA */
+  SFM_METRIC_L2_F32  = 1,  /* float32 [n,dim]: sequential float32 sum of (a-b)^2 (general floats)   */
+  SFM_METRIC_HAMMING = 2   /* uint8 [n,dim] bit strings (ORB: dim=32), popcount                      */
+};
+
+int sfm_match_workspace_bytes(int metric, int64_t nq, int64_t nt, int dim, int64_t* bytes_host);
+
+/* Per query row: two nearest train rows (idx1/d1 nearest), ties -> lower train index.
+ * d1/d2: L2 = sqrtf(d^2), Hamming = bit count.  Needs nt >= 2. */
+int sfm_match_knn2(sfm_handle h, int metric, const void* q, int64_t nq, const void* t, int64_t nt,
+                   int dim, int32_t* idx1, int32_t* idx2, float* d1, float* d2,
+                   void* workspace, int64_t workspace_bytes);
+
+/* Lowe ratio test `(double)d1 < ratio * (double)d2` (find_matches.py:152) and compaction in
+ * query order.  query_idx/train_idx/dist have room for nq entries; *n_matches is a device int64. */
+int sfm_match_ratio(sfm_handle h, int64_t nq, const int32_t* idx1, const float* d1, const float* d2,
+                    double ratio, int32_t* query_idx, int32_t* train_idx, float* dist,
+                    int64_t* n_matches, void* workspace, int64_t workspace_bytes);
+
+/* float32 descriptors whose every value is an integer in [0,255] (what SIFT emits) -> uint8 copy;
+ * *all_integral (device int32) is 0 if any value is not such an integer. */
+int sfm_match_f32_to_u8(sfm_handle h, const float* src, int64_t n_elems, uint8_t* dst, int32_t* all_integral);
+
+/* ------------------------------------------------------------------ bundle adjustment
+ * Replaces what scipy.optimize.least_squares does for bundle_adjust: evaluation of the
+ * closure `objective` (sfm_reconstruction.py:472-501), its Jacobian, the Huber scaling
+ * (scipy _lsq/common.py:720-731) and the damped step (H + alpha I) p = -g of the exact
+ * trust-region solver (scipy _lsq/common.py:57-168), done block-sparse with a Schur complement.
+ * The trust-region state machine (scipy _lsq/trf.py:401-560) stays on the host (sfm_amd/trf.py)
+ * and calls these stages; between stages it may all-reduce the regions named `reduce_*`
+ * across ranks (points sharded over GPUs, cameras replicated).
+ *
+ * Parameter vector x = [cams (n_cams*cam_dim) | pts (n_pts*3)] float64, camera block
+ * [rvec(3), t(3), fx, fy, cx, cy] for cam_dim 10 (reference, :416-427) or [rvec, t] for 6.
+ * Observations are in the reference's point-major order (:430-435): pt_idx non-decreasing.
+ */
+typedef struct {
+  int32_t n_cams, n_pts, cam_dim, apply_reg;   /* apply_reg: add the 4 regulariser rows per camera (:489-499); rank 0 only */
+  int64_t n_obs;
+  const int32_t* cam_idx;    /* [n_obs] */
+  const int32_t* pt_idx;     /* [n_obs] non-decreasing */
+  const double*  uv;         /* [n_obs*2] pixel each observation is compared with */
+  const int32_t* pt_ptr;     /* [n_pts+1]  obs range of each point (track) */
+  const int32_t* cam_ptr;    /* [n_cams+1] ranges into cam_obs */
+  const int32_t* cam_obs;    /* [n_obs] observation ids grouped by camera, ascending inside a camera */
+  const int32_t* blk_ptr;    /* [n_cams*(n_cams+1)/2 + 1] ranges into pair_k/pair_k2, block (c<=c2) at c*n_cams - c*(c-1)/2 + (c2-c) */
+  const int32_t* pair_k;     /* [n_pairs] observation of camera c  on a shared track */
+  const int32_t* pair_k2;    /* [n_pairs] observation of camera c2 on the same track */
+  int64_t n_pairs;
+  double fx0, fy0, cx0, cy0; /* pre-BA self.K (:492-497); intrinsics of every camera when cam_dim == 6 */
+  double width, height, reg_weight;
+  void*   workspace;
+  int64_t workspace_bytes;
+} sfm_ba_problem;
+
+/* Byte offsets into the workspace of the regions the host reads or all-reduces. */
+typedef struct {
+  int64_t total_bytes;
+  int64_t rec_off, rec_stride;      /* per observation: Jc~ [2][cam_dim], Jp~ [2][3], f~ [2] (robust-scaled), doubles */
+  int64_t B_off, gc_off;            /* [n_cams][cam_dim][cam_dim], [n_cams][cam_dim]   (this rank's partial sums) */
+  int64_t Cp_off, gp_off;           /* [n_pts][6] (xx,xy,xz,yy,yz,zz), [n_pts][3] */
+  int64_t reduce_lin_off, reduce_lin_count;     /* doubles: [gc copy (n_cams*cam_dim) | cost | ||gp||^2 ]  SUM */
+  int64_t gmax_off;                              /* 1 double: max |gp|                                       MAX */
+  int64_t reduce_S_off, reduce_S_count;         /* doubles: [S (n x n, n = n_cams*cam_dim) | r (n)]          SUM */
+  int64_t reduce_q_off, reduce_q_count;         /* doubles: [rhs2 (n) | ||p_pts||^2 | p_pts^T C_a^-1 p_pts]  SUM */
+  int64_t reduce_step_off, reduce_step_count;   /* doubles: [||J~ s||^2 | f~^T J~ s | cost(x+s) | ||s_pts||^2 | ||x_pts+s_pts||^2 ] SUM */
+  int64_t pc_off, pp_off;           /* camera / point part of p = -(H + alpha I)^-1 g */
+  int64_t scalars_off;              /* 16 doubles, see SFM_SC_* */
+  int64_t G_off;                    /* [n_obs][3][cam_dim] */
+} sfm_ba_layout;
+
+enum { SFM_SC_COST = 0, SFM_SC_GNORM2 = 1, SFM_SC_GINF = 2, SFM_SC_PNORM2 = 3, SFM_SC_PQ = 4,
+       SFM_SC_JS2 = 5, SFM_SC_GTS = 6, SFM_SC_COST_NEW = 7, SFM_SC_SNORM2 = 8, SFM_SC_XNEW_NORM2 = 9,
+       SFM_SC_CHOL_FAIL = 10, SFM_SC_COUNT = 16 };
+
+int sfm_ba_get_layout(int32_t n_cams, int32_t n_pts, int64_t n_obs, int32_t cam_dim, sfm_ba_layout* out_host);
+
+/* cost(x) = 1/2 sum rho(f_i^2) (Huber, per scalar) -> partial into reduce_step[2] (this rank's observations). */
+int sfm_ba_cost(sfm_handle h, const sfm_ba_problem* p, const double* x);
+/* per-observation reprojection error ||proj - uv||_2.  shared_k != 0: ONE shared K = (fx0,fy0,cx0,cy0)
+ * for every camera (compute_reconstruction_stats, :582-631); shared_k == 0: each camera's own
+ * intrinsics when cam_dim == 10 (the reprojection rows of `objective`, :478-486). */
+int sfm_ba_reproj_errors(sfm_handle h, const sfm_ba_problem* p, const double* x, int shared_k, double* err_out);
+
+/* Linearise at x: records, B, gc, Cp, gp, cost -> reduce_lin region (+ gmax). */
+int sfm_ba_linearize(sfm_handle h, const sfm_ba_problem* p, const double* x);
+/* After the host has (all-)reduced reduce_lin and gmax: scalars COST, GNORM2, GINF. */
+int sfm_ba_finish_linearize(sfm_handle h, const sfm_ba_problem* p);
+
+/* Damped solve in three stages around two reductions. */
+int sfm_ba_schur_build(sfm_handle h, const sfm_ba_problem* p, double alpha);          /* -> reduce_S (partial) */
+int sfm_ba_schur_solve(sfm_handle h, const sfm_ba_problem* p, double alpha, int want_q); /* chol, p_c, p_p; -> reduce_q (partial) */
+int sfm_ba_finish_solve(sfm_handle h, const sfm_ba_problem* p, int want_q);              /* scalars PNORM2 (and PQ) */
+
+/* s = scale * p;  x_new = x + s;  partial sums for the predicted reduction and cost(x_new) -> reduce_step. */
+int sfm_ba_step(sfm_handle h, const sfm_ba_problem* p, const double* x, double scale, double* x_new);
+int sfm_ba_finish_step(sfm_handle h, const sfm_ba_problem* p, const double* x, double scale, const double* x_new);
+
+/* Copy the SFM_SC_COUNT scalars to the host (synchronises the stream). */
+int sfm_ba_read_scalars(sfm_handle h, const sfm_ba_problem* p, double* out_host);
+
+/* Dense SPD helpers used by the solve, exported for tests: in-place lower Cholesky of a [n][n]
+ * row-major matrix and solves with the factor.  fail_flag: device int32, set when a pivot <= 0. */
+int sfm_dense_cholesky(sfm_handle h, double* a, int32_t n, int32_t* fail_flag);
+int sfm_dense_trsv(sfm_handle h, const double* l, int32_t n, double* b, int transpose);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,1224 @@
+// Bundle-adjustment stages for gfx950 (MI355X): residual + analytic Jacobian + Huber row
+// scaling, block accumulation, damped Schur-complement solve.  fp64 throughout.
+//
+// What is computed (and for which reference lines) is documented in include/sfm_amd.h and
+// DESIGN.md; the arithmetic mirrors oracle/ba_oracle.py statement by statement where the
+// order of operations matters (Rodrigues coefficients, Huber scaling).
+//
+// Data layout in HBM (all inside the caller's workspace, see ba_layout()):
+//   rec    [N][2D+8]  per observation, point-major: Jc~ rows (2xD), Jp~ rows (2x3), f~ (2)
+//   G      [N][3][D]  per observation, per alpha: W_k L_j^-T  (L_j L_j^T = C_j + alpha I)
+//   S | r  [(n+1)][n] reduced camera system with its right-hand side as a bordered row
+// Observations of one point (a track) are contiguous; cameras are reached through cam_obs.
+#include "common.h"
+
+typedef double v4d __attribute__((ext_vector_type(4)));
+
+#define EPS_D 2.220446049250313e-16
+#define SQRT_EPS_D 1.4901161193847656e-08
+#define CAMPRE 44   // R[9] dR[27] t[3] fx fy cx cy pad
+
+// ------------------------------------------------------------------------------------ layout
+struct Lay {   // offsets in doubles
+  int64_t rec, campre, campre2, B, gc, Cp, gp, Linv, e, v, tmp3, G, red_lin, gmax, red_S, red_q,
+      red_step, pc, pp, y, scalars, part_obs, part_pt, part_x, cost_reg, regrec, panel, flag, total;
+  int64_t nblk_obs, nblk_pt;
+};
+
+static Lay ba_layout(int64_t C, int64_t P, int64_t N, int64_t D) {
+  Lay L;
+  int64_t o = 0, n = C * D;
+  auto take = [&](int64_t cnt) { int64_t r = o; o = align_up(o + cnt, 32); return r; };
+  L.nblk_obs = (N + 255) / 256;
+  L.nblk_pt = (P + 255) / 256;
+  L.rec = take(N * (2 * D + 8));
+  L.campre = take(C * CAMPRE);
+  L.campre2 = take(C * CAMPRE);
+  L.B = take(C * D * D);
+  L.gc = take(n);
+  L.Cp = take(P * 6);
+  L.gp = take(P * 3);
+  L.Linv = take(P * 6);
+  L.e = take(P * 3);
+  L.v = take(P * 3);
+  L.tmp3 = take(N * 3);
+  L.G = take(N * 3 * D);
+  L.red_lin = take(n + 2);
+  L.gmax = take(1);
+  L.red_S = take(n * n + n);
+  L.red_q = take(n + 2);
+  L.red_step = take(8);
+  L.pc = take(n);
+  L.pp = take(P * 3);
+  L.y = take(n);
+  L.scalars = take(SFM_SC_COUNT);
+  L.part_obs = take(L.nblk_obs * 2 * 4 + 4);
+  L.part_pt = take(L.nblk_pt * 4);
+  L.part_x = take(((n + 3 * P + 255) / 256) * 2 + 2);
+  L.cost_reg = take(C * 4);
+  L.regrec = take(C * 20);
+  L.panel = take((n + 1) * 32);
+  L.flag = take(4);
+  L.total = o;
+  return L;
+}
+
+extern "C" int sfm_ba_get_layout(int32_t n_cams, int32_t n_pts, int64_t n_obs, int32_t cam_dim,
+                                 sfm_ba_layout* out) {
+  if (!out || n_cams < 1 || n_pts < 0 || n_obs < 0 || (cam_dim != 6 && cam_dim != 10)) return SFM_ERR_ARG;
+  Lay L = ba_layout(n_cams, n_pts, n_obs, cam_dim);
+  int64_t n = (int64_t)n_cams * cam_dim;
+  out->total_bytes = L.total * 8;
+  out->rec_off = L.rec * 8; out->rec_stride = (2 * cam_dim + 8) * 8;
+  out->B_off = L.B * 8; out->gc_off = L.gc * 8;
+  out->Cp_off = L.Cp * 8; out->gp_off = L.gp * 8;
+  out->reduce_lin_off = L.red_lin * 8; out->reduce_lin_count = n + 2;
+  out->gmax_off = L.gmax * 8;
+  out->reduce_S_off = L.red_S * 8; out->reduce_S_count = n * n + n;
+  out->reduce_q_off = L.red_q * 8; out->reduce_q_count = n + 2;
+  out->reduce_step_off = L.red_step * 8; out->reduce_step_count = 5;
+  out->pc_off = L.pc * 8; out->pp_off = L.pp * 8;
+  out->scalars_off = L.scalars * 8;
+  out->G_off = L.G * 8;
+  return SFM_OK;
+}
+
+// ------------------------------------------------------------------------------------ helpers
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+  return v;   // valid in lane 0
+}
+__device__ __forceinline__ double wave_max(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_down(v, o, 64));
+  return v;
+}
+// Sum over a 256-thread block, fixed order; result valid in thread 0.  s: >= 4 doubles of LDS.
+__device__ __forceinline__ double block_sum256(double v, double* s) {
+  v = wave_sum(v);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) s[threadIdx.x >> 6] = v;
+  __syncthreads();
+  return s[0] + s[1] + s[2] + s[3];
+}
+__device__ __forceinline__ double block_max256(double v, double* s) {
+  v = wave_max(v);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) s[threadIdx.x >> 6] = v;
+  __syncthreads();
+  return fmax(fmax(s[0], s[1]), fmax(s[2], s[3]));
+}
+
+// Huber, per scalar residual, exactly as scipy least_squares.py:169-178 + common.py:720-731:
+// returns rho0; scale = sqrt(max(rho1 + 2 rho2 f^2, EPS)); ft = f * rho1 / scale.
+__device__ __forceinline__ double huber_row(double f, double& scale, double& ft) {
+  double z = f * f;
+  if (z <= 1.0) { scale = 1.0; ft = f; return z; }
+  double sz = sqrt(z);
+  double rho1 = 1.0 / sz;
+  // rho1 + 2*rho2*z with rho2 = -0.5 z^-1.5 is 0 up to rounding -> clamped to EPS
+  scale = SQRT_EPS_D;
+  ft = f * rho1 / SQRT_EPS_D;
+  return 2.0 * sz - 1.0;
+}
+__device__ __forceinline__ double huber_rho0(double f) {
+  double z = f * f;
+  return z <= 1.0 ? z : 2.0 * sqrt(z) - 1.0;
+}
+
+__device__ __forceinline__ void mat3_mul(const double* A, const double* Bm, double* Cm) {
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j)
+      Cm[i * 3 + j] = A[i * 3] * Bm[j] + A[i * 3 + 1] * Bm[3 + j] + A[i * 3 + 2] * Bm[6 + j];
+}
+
+// ------------------------------------------------------------------------------------ per-camera precompute
+// R = I + a[r]x + b[r]x^2 and dR/dr_i (same series/closed-form split as the oracle's _rod_coeffs).
+template <int D>
+__global__ void k_campre(const double* __restrict__ cams, int C, double fx0, double fy0, double cx0,
+                         double cy0, double* __restrict__ out) {
+  int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const double* p = cams + (size_t)c * D;
+  double r[3] = {p[0], p[1], p[2]};
+  double th2 = r[0] * r[0] + r[1] * r[1] + r[2] * r[2];
+  double a, b, a1, b1;
+  if (th2 < 1e-4) {
+    double z = th2;
+    a = 1.0 - z / 6.0 + z * z / 120.0;
+    b = 0.5 - z / 24.0 + z * z / 720.0;
+    a1 = -1.0 / 3.0 + z / 30.0 - z * z / 840.0;
+    b1 = -1.0 / 12.0 + z / 180.0 - z * z / 6720.0;
+  } else {
+    double t = sqrt(th2), s, co;
+    sincos(t, &s, &co);
+    a = s / t;
+    b = (1.0 - co) / th2;
+    a1 = (t * co - s) / (th2 * t);
+    b1 = (t * s - 2.0 * (1.0 - co)) / (th2 * th2);
+  }
+  double S[9] = {0, -r[2], r[1], r[2], 0, -r[0], -r[1], r[0], 0};
+  double S2[9];
+  mat3_mul(S, S, S2);
+  double* o = out + (size_t)c * CAMPRE;
+#pragma unroll
+  for (int i = 0; i < 9; ++i) o[i] = ((i % 4 == 0) ? 1.0 : 0.0) + a * S[i] + b * S2[i];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    double e[3] = {0, 0, 0};
+    e[i] = 1.0;
+    double E[9] = {0, -e[2], e[1], e[2], 0, -e[0], -e[1], e[0], 0};
+    double ES[9], SE[9];
+    mat3_mul(E, S, ES);
+    mat3_mul(S, E, SE);
+#pragma unroll
+    for (int q = 0; q < 9; ++q)
+      o[9 + i * 9 + q] = a * E[q] + b * (ES[q] + SE[q]) + (a1 * r[i]) * S[q] + (b1 * r[i]) * S2[q];
+  }
+  o[36] = p[3]; o[37] = p[4]; o[38] = p[5];
+  if (D == 10) { o[39] = p[6]; o[40] = p[7]; o[41] = p[8]; o[42] = p[9]; }
+  else { o[39] = fx0; o[40] = fy0; o[41] = cx0; o[42] = cy0; }
+  o[43] = 0.0;
+}
+
+// ------------------------------------------------------------------------------------ linearise: per observation
+// One thread per observation (point-major).  Residual (sfm_reconstruction.py:453-470,486), analytic
+// 2x(D+3) Jacobian, Huber row scaling; the record is transposed through LDS so
+// the 2D+8 doubles of 256 observations leave the CU as one contiguous, fully coalesced stream.
+template <int D>
+__global__ __launch_bounds__(256) void k_lin_obs(int64_t N, const int* __restrict__ cam_idx,
+                                                 const int* __restrict__ pt_idx,
+                                                 const double* __restrict__ uv,
+                                                 const double* __restrict__ pts,
+                                                 const double* __restrict__ campre,
+                                                 double* __restrict__ rec, double* __restrict__ part) {
+  constexpr int REC = 2 * D + 8, LDR = REC + 1;
+  __shared__ double s_rec[256 * LDR];
+  __shared__ double s_red[4];
+  const int tid = threadIdx.x;
+  const int64_t k0 = (int64_t)blockIdx.x * 256;
+  const int64_t k = k0 + tid;
+  double cost = 0.0;
+  if (k < N) {
+    const int c = cam_idx[k], j = pt_idx[k];
+    const double* cp = campre + (size_t)c * CAMPRE;
+    const double X0 = pts[3 * (size_t)j], X1 = pts[3 * (size_t)j + 1], X2 = pts[3 * (size_t)j + 2];
+    double R[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) R[i] = cp[i];
+    const double Y0 = R[0] * X0 + R[1] * X1 + R[2] * X2 + cp[36];
+    const double Y1 = R[3] * X0 + R[4] * X1 + R[5] * X2 + cp[37];
+    const double Y2 = R[6] * X0 + R[7] * X1 + R[8] * X2 + cp[38];
+    const double fx = cp[39], fy = cp[40], cx = cp[41], cy = cp[42];
+    const double iz = 1.0 / Y2, xn = Y0 * iz, yn = Y1 * iz;
+    const double f0 = fx * xn + cx - uv[2 * k], f1 = fy * yn + cy - uv[2 * k + 1];
+    double s0, s1, ft0, ft1;
+    cost = 0.5 * (huber_row(f0, s0, ft0) + huber_row(f1, s1, ft1));
+    // Pi = d(u,v)/d(x,y,z), already multiplied by the robust row scale
+    const double p00 = s0 * fx * iz, p02 = -s0 * fx * xn * iz;
+    const double p11 = s1 * fy * iz, p12 = -s1 * fy * yn * iz;
+    double* my = &s_rec[tid * LDR];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      const double* dR = cp + 9 + i * 9;
+      const double d0 = dR[0] * X0 + dR[1] * X1 + dR[2] * X2;
+      const double d1 = dR[3] * X0 + dR[4] * X1 + dR[5] * X2;
+      const double d2 = dR[6] * X0 + dR[7] * X1 + dR[8] * X2;
+      my[i] = p00 * d0 + p02 * d2;
+      my[D + i] = p11 * d1 + p12 * d2;
+    }
+    my[3] = p00; my[4] = 0.0; my[5] = p02;
+    my[D + 3] = 0.0; my[D + 4] = p11; my[D + 5] = p12;
+    if (D == 10) {
+      my[6] = s0 * xn; my[7] = 0.0; my[8] = s0; my[9] = 0.0;
+      my[D + 6] = 0.0; my[D + 7] = s1 * yn; my[D + 8] = 0.0; my[D + 9] = s1;
+    }
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+      my[2 * D + q] = p00 * R[q] + p02 * R[6 + q];
+      my[2 * D + 3 + q] = p11 * R[3 + q] + p12 * R[6 + q];
+    }
+    my[2 * D + 6] = ft0;
+    my[2 * D + 7] = ft1;
+  }
+  double tot = block_sum256(cost, s_red);   // contains the barrier that publishes s_rec
+  if (tid == 0) part[blockIdx.x] = tot;
+  const int64_t nvalid = (N - k0) < 256 ? (N - k0) : 256;
+  const int total = (int)nvalid * REC;
+  double* outp = rec + (size_t)k0 * REC;
+  for (int i = tid; i < total; i += 256) {
+    const int t = i / REC, q = i - t * REC;
+    outp[i] = s_rec[t * LDR + q];
+  }
+}
+
+// per point: C_j = sum Jp~^T Jp~ (packed xx,xy,xz,yy,yz,zz), g_pj = sum Jp~^T f~ ; block partials of
+// ||g_p||^2 and max|g_p|.
+template <int D>
+__global__ __launch_bounds__(256) void k_point_blocks(int P, const int* __restrict__ pt_ptr,
+                                                      const double* __restrict__ rec,
+                                                      double* __restrict__ Cp, double* __restrict__ gp,
+                                                      double* __restrict__ part) {
+  constexpr int REC = 2 * D + 8;
+  __shared__ double s_red[4];
+  const int j = blockIdx.x * 256 + threadIdx.x;
+  double g2 = 0.0, gm = 0.0;
+  if (j < P) {
+    double c0 = 0, c1 = 0, c2 = 0, c3 = 0, c4 = 0, c5 = 0, g0 = 0, g1 = 0, g2v = 0;
+    for (int k = pt_ptr[j]; k < pt_ptr[j + 1]; ++k) {
+      const double* r = rec + (size_t)k * REC + 2 * D;
+      const double a0 = r[0], a1 = r[1], a2 = r[2], b0 = r[3], b1 = r[4], b2 = r[5], f0 = r[6], f1 = r[7];
+      c0 += a0 * a0 + b0 * b0; c1 += a0 * a1 + b0 * b1; c2 += a0 * a2 + b0 * b2;
+      c3 += a1 * a1 + b1 * b1; c4 += a1 * a2 + b1 * b2; c5 += a2 * a2 + b2 * b2;
+      g0 += a0 * f0 + b0 * f1; g1 += a1 * f0 + b1 * f1; g2v += a2 * f0 + b2 * f1;
+    }
+    double* co = Cp + (size_t)j * 6;
+    co[0] = c0; co[1] = c1; co[2] = c2; co[3] = c3; co[4] = c4; co[5] = c5;
+    gp[(size_t)j * 3] = g0; gp[(size_t)j * 3 + 1] = g1; gp[(size_t)j * 3 + 2] = g2v;
+    g2 = g0 * g0 + g1 * g1 + g2v * g2v;
+    gm = fmax(fabs(g0), fmax(fabs(g1), fabs(g2v)));
+  }
+  double t2 = block_sum256(g2, s_red);
+  double tm = block_max256(gm, s_red);
+  if (threadIdx.x == 0) { part[blockIdx.x * 2] = t2; part[blockIdx.x * 2 + 1] = tm; }
+}
+
+// per camera: B_c = sum Jc~^T Jc~ (DxD), g_c = sum Jc~^T f~ over the camera's observations.
+// One workgroup per camera; tiles of 64 observations are gathered into LDS, thread e owns B[a][b].
+template <int D>
+__global__ __launch_bounds__(256) void k_cam_blocks(const int* __restrict__ cam_ptr,
+                                                    const int* __restrict__ cam_obs,
+                                                    const double* __restrict__ rec,
+                                                    double* __restrict__ B, double* __restrict__ gc) {
+  constexpr int REC = 2 * D + 8, W = 2 * D + 2, LDW = W + 1;
+  __shared__ double s[64 * LDW];
+  const int c = blockIdx.x, tid = threadIdx.x;
+  const int beg = cam_ptr[c], end = cam_ptr[c + 1];
+  const int a = tid / D, b = tid % D;
+  double acc = 0.0;
+  for (int base = beg; base < end; base += 64) {
+    const int cnt = (end - base) < 64 ? (end - base) : 64;
+    __syncthreads();
+    for (int i = tid; i < cnt * W; i += 256) {
+      const int o = i / W, q = i - o * W;
+      const int k = cam_obs[base + o];
+      s[o * LDW + q] = rec[(size_t)k * REC + (q < 2 * D ? q : q + 6)];
+    }
+    __syncthreads();
+    if (tid < D * D) {
+      for (int o = 0; o < cnt; ++o) {
+        const double* r = &s[o * LDW];
+        acc += r[a] * r[b] + r[D + a] * r[D + b];
+      }
+    } else if (tid < D * D + D) {
+      const int aa = tid - D * D;
+      for (int o = 0; o < cnt; ++o) {
+        const double* r = &s[o * LDW];
+        acc += r[aa] * r[2 * D] + r[D + aa] * r[2 * D + 1];
+      }
+    }
+  }
+  if (tid < D * D) B[(size_t)c * D * D + tid] = acc;
+  else if (tid < D * D + D) gc[(size_t)c * D + (tid - D * D)] = acc;
+}
+
+// Regulariser rows of sfm_reconstruction.py:489-499 (cam_dim 10): residual, Jacobian w.r.t.
+// (fx,fy,cx,cy), Huber scaling; adds into B_c / g_c, keeps the scaled rows for the step stage.
+__global__ void k_cam_reg(int C, const double* __restrict__ cams, double fx0, double cx0, double cy0,
+                          double width, double height, double w, double* __restrict__ B,
+                          double* __restrict__ gc, double* __restrict__ cost_reg,
+                          double* __restrict__ regrec) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const double* p = cams + (size_t)c * 10;
+  const double fx = p[6], fy = p[7], cx = p[8], cy = p[9];
+  double f[4] = {(fx - fx0) / fx0 * w, (fy - fx) / fx * w, (cx - cx0) / width * w, (cy - cy0) / height * w};
+  double J[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) J[i] = 0.0;
+  J[0] = w / fx0;
+  J[4] = -w * fy / (fx * fx); J[5] = w / fx;
+  J[10] = w / width;
+  J[15] = w / height;
+  double cost = 0.0, ft[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    double sc;
+    cost += huber_row(f[r], sc, ft[r]);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) J[r * 4 + q] *= sc;
+  }
+  cost_reg[c] = 0.5 * cost;
+  double* Bc = B + (size_t)c * 100;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    double g = 0.0;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) g += J[r * 4 + i] * ft[r];
+    gc[(size_t)c * 10 + 6 + i] += g;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      double hsum = 0.0;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) hsum += J[r * 4 + i] * J[r * 4 + q];
+      Bc[(6 + i) * 10 + 6 + q] += hsum;
+    }
+  }
+  double* rr = regrec + (size_t)c * 20;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) rr[i] = J[i];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) rr[16 + r] = ft[r];
+}
+
+// Fixed-order sum of block partials -> reduce_lin = [gc copy | cost | ||gp||^2], gmax.
+__global__ __launch_bounds__(256) void k_lin_finalize(int n, const double* __restrict__ gc,
+                                                      const double* __restrict__ part_obs, int nblk_obs,
+                                                      const double* __restrict__ part_pt, int nblk_pt,
+                                                      const double* __restrict__ cost_reg, int n_reg,
+                                                      double* __restrict__ red_lin, double* __restrict__ gmax) {
+  __shared__ double s_red[4];
+  const int tid = threadIdx.x;
+  for (int i = tid; i < n; i += 256) red_lin[i] = gc[i];
+  double c = 0.0, g2 = 0.0, gm = 0.0;
+  for (int i = tid; i < nblk_obs; i += 256) c += part_obs[i];
+  for (int i = tid; i < n_reg; i += 256) c += cost_reg[i];
+  for (int i = tid; i < nblk_pt; i += 256) { g2 += part_pt[2 * i]; gm = fmax(gm, part_pt[2 * i + 1]); }
+  double ct = block_sum256(c, s_red);
+  double g2t = block_sum256(g2, s_red);
+  double gmt = block_max256(gm, s_red);
+  if (tid == 0) { red_lin[n] = ct; red_lin[n + 1] = g2t; gmax[0] = gmt; }
+}
+
+__global__ __launch_bounds__(256) void k_finish_linearize(int n, const double* __restrict__ red_lin,
+                                                          const double* __restrict__ gmax,
+                                                          double* __restrict__ sc) {
+  __shared__ double s_red[4];
+  double g2 = 0.0, gm = 0.0;
+  for (int i = threadIdx.x; i < n; i += 256) { double v = red_lin[i]; g2 += v * v; gm = fmax(gm, fabs(v)); }
+  double g2t = block_sum256(g2, s_red);
+  double gmt = block_max256(gm, s_red);
+  if (threadIdx.x == 0) {
+    sc[SFM_SC_COST] = red_lin[n];
+    sc[SFM_SC_GNORM2] = g2t + red_lin[n + 1];
+    sc[SFM_SC_GINF] = fmax(gmt, gmax[0]);
+  }
+}
+
+// ------------------------------------------------------------------------------------ damped solve: point side
+// L_j L_j^T = C_j + alpha I ; stores M = L_j^-1 (lower, packed m00 m10 m11 m20 m21 m22) and e_j = M g_pj.
+__global__ void k_point_factor(int P, double alpha, const double* __restrict__ Cp,
+                               const double* __restrict__ gp, double* __restrict__ Linv,
+                               double* __restrict__ e) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= P) return;
+  const double* c = Cp + (size_t)j * 6;
+  const double a00 = c[0] + alpha, a10 = c[1], a20 = c[2], a11 = c[3] + alpha, a21 = c[4], a22 = c[5] + alpha;
+  const double l00 = sqrt(a00), l10 = a10 / l00, l20 = a20 / l00;
+  const double l11 = sqrt(a11 - l10 * l10), l21 = (a21 - l20 * l10) / l11;
+  const double l22 = sqrt(a22 - l20 * l20 - l21 * l21);
+  const double m00 = 1.0 / l00, m11 = 1.0 / l11, m22 = 1.0 / l22;
+  const double m10 = -l10 * m00 * m11, m21 = -l21 * m11 * m22;
+  const double m20 = -(l20 * m00 + l21 * m10) * m22;
+  double* o = Linv + (size_t)j * 6;
+  o[0] = m00; o[1] = m10; o[2] = m11; o[3] = m20; o[4] = m21; o[5] = m22;
+  const double g0 = gp[(size_t)j * 3], g1 = gp[(size_t)j * 3 + 1], g2 = gp[(size_t)j * 3 + 2];
+  e[(size_t)j * 3] = m00 * g0;
+  e[(size_t)j * 3 + 1] = m10 * g0 + m11 * g1;
+  e[(size_t)j * 3 + 2] = m20 * g0 + m21 * g1 + m22 * g2;
+}
+
+// G_k[m][a] = sum_r Jc~[r][a] * V[r][m],  V = Jp~ M^T (2x3).  One thread per output element: reads of
+// Jc~ and writes of G are both coalesced over a.
+template <int D>
+__global__ __launch_bounds__(256) void k_build_G(int64_t total, const int* __restrict__ pt_idx,
+                                                 const double* __restrict__ rec,
+                                                 const double* __restrict__ Linv, double* __restrict__ G) {
+  constexpr int REC = 2 * D + 8;
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= total) return;
+  const int64_t k = i / (3 * D);
+  const int q = (int)(i - k * (3 * D));
+  const int m = q / D, a = q - m * D;
+  const double* r = rec + (size_t)k * REC;
+  const double* M = Linv + (size_t)pt_idx[k] * 6;
+  const double* jp = r + 2 * D;
+  double v0, v1;
+  if (m == 0) { v0 = jp[0] * M[0]; v1 = jp[3] * M[0]; }
+  else if (m == 1) { v0 = jp[0] * M[1] + jp[1] * M[2]; v1 = jp[3] * M[1] + jp[4] * M[2]; }
+  else { v0 = jp[0] * M[3] + jp[1] * M[4] + jp[2] * M[5]; v1 = jp[3] * M[3] + jp[4] * M[4] + jp[5] * M[5]; }
+  G[i] = r[a] * v0 + r[D + a] * v1;
+}
+
+// Reduced camera system, one wavefront per camera pair (c <= c2):
+//   S[c][c2] = [c == c2] B_c - sum_{(k,k2) on a shared track} G_k G_k2^T        (+ mirrored block)
+// as a K = 4 (3 used) x n_pairs contraction on v_mfma_f64_16x16x4_f64: lane l feeds A[row l&15][k l>>4]
+// = G_k[m = l>>4][row], B likewise from G_k2; C/D: col = l&15, row = (l>>4) + 4*reg.
+template <int D>
+__global__ __launch_bounds__(256) void k_schur_blocks(int C, const int* __restrict__ blk_ptr,
+                                                      const int* __restrict__ pair_k,
+                                                      const int* __restrict__ pair_k2,
+                                                      const double* __restrict__ G,
+                                                      const double* __restrict__ B, double* __restrict__ S) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int c = blockIdx.x;
+  const int c2 = c + blockIdx.y * 4 + w;
+  if (c2 >= C) return;
+  const int64_t blk = (int64_t)c * C - (int64_t)c * (c - 1) / 2 + (c2 - c);
+  const int beg = blk_ptr[blk], end = blk_ptr[blk + 1];
+  const int row = lane & 15, m = lane >> 4;
+  const bool valid = (row < D) && (m < 3);
+  const int off = m * D + row;
+  v4d acc = {0.0, 0.0, 0.0, 0.0};
+  int p = beg;
+  for (; p + 4 <= end; p += 4) {
+    double a[4], b[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int k = pair_k[p + u], k2 = pair_k2[p + u];
+      a[u] = valid ? G[(size_t)k * (3 * D) + off] : 0.0;
+      b[u] = valid ? G[(size_t)k2 * (3 * D) + off] : 0.0;
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[u], b[u], acc, 0, 0, 0);
+  }
+  for (; p < end; ++p) {
+    const int k = pair_k[p], k2 = pair_k2[p];
+    const double a = valid ? G[(size_t)k * (3 * D) + off] : 0.0;
+    const double b = valid ? G[(size_t)k2 * (3 * D) + off] : 0.0;
+    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
+  }
+  const int n = C * D;
+  const int col = lane & 15;
+  if (col < D) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int rr = (lane >> 4) + 4 * i;
+      if (rr < D) {
+        double v = -acc[i];
+        if (c == c2) v += B[(size_t)c * D * D + rr * D + col];
+        S[(size_t)(c * D + rr) * n + c2 * D + col] = v;
+        if (c != c2) S[(size_t)(c2 * D + col) * n + c * D + rr] = v;
+      }
+    }
+  }
+}
+
+// out[c][a] = (base ? base[c][a] : 0) - sum_{k in camera c} sum_m G_k[m][a] vec[pt(k)][m]
+// One workgroup per camera: 16 observation slots x 16 lanes (a); slots reduced through LDS in fixed order.
+template <int D>
+__global__ __launch_bounds__(256) void k_cam_reduce(const int* __restrict__ cam_ptr,
+                                                    const int* __restrict__ cam_obs,
+                                                    const int* __restrict__ pt_idx,
+                                                    const double* __restrict__ G,
+                                                    const double* __restrict__ vec,
+                                                    const double* __restrict__ base, double* __restrict__ out) {
+  __shared__ double s[16 * 16];
+  const int c = blockIdx.x, tid = threadIdx.x;
+  const int slot = tid >> 4, a = tid & 15;
+  double acc = 0.0;
+  if (a < D) {
+    for (int i = cam_ptr[c] + slot; i < cam_ptr[c + 1]; i += 16) {
+      const int k = cam_obs[i];
+      const double* g = G + (size_t)k * (3 * D) + a;
+      const double* v = vec + (size_t)pt_idx[k] * 3;
+      acc += g[0] * v[0] + g[D] * v[1] + g[2 * D] * v[2];
+    }
+  }
+  s[slot * 16 + a] = acc;
+  __syncthreads();
+  if (tid < D) {
+    double t = 0.0;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) t += s[q * 16 + tid];
+    out[(size_t)c * D + tid] = (base ? base[(size_t)c * D + tid] : 0.0) - t;
+  }
+}
+
+// tmp3[k][m] = sum_a G_k[m][a] p_c[cam(k)][a]
+template <int D>
+__global__ __launch_bounds__(256) void k_obs_Gtp(int64_t total, const int* __restrict__ cam_idx,
+                                                 const double* __restrict__ G,
+                                                 const double* __restrict__ pc, double* __restrict__ tmp3) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= total) return;
+  const int64_t k = i / 3;
+  const double* g = G + (size_t)i * D;
+  const double* p = pc + (size_t)cam_idx[k] * D;
+  double t = 0.0;
+#pragma unroll
+  for (int a = 0; a < D; ++a) t += g[a] * p[a];
+  tmp3[i] = t;
+}
+
+// p_pj = -M^T (e_j + sum_track tmp3),  v_j = M p_pj ; block partials of ||p_p||^2 and ||v||^2.
+__global__ __launch_bounds__(256) void k_backsub(int P, const int* __restrict__ pt_ptr,
+                                                 const double* __restrict__ tmp3,
+                                                 const double* __restrict__ Linv,
+                                                 const double* __restrict__ e, double* __restrict__ pp,
+                                                 double* __restrict__ v, double* __restrict__ part) {
+  __shared__ double s_red[4];
+  const int j = blockIdx.x * 256 + threadIdx.x;
+  double p2 = 0.0, v2 = 0.0;
+  if (j < P) {
+    double u0 = e[(size_t)j * 3], u1 = e[(size_t)j * 3 + 1], u2 = e[(size_t)j * 3 + 2];
+    for (int k = pt_ptr[j]; k < pt_ptr[j + 1]; ++k) {
+      u0 += tmp3[(size_t)k * 3]; u1 += tmp3[(size_t)k * 3 + 1]; u2 += tmp3[(size_t)k * 3 + 2];
+    }
+    const double* M = Linv + (size_t)j * 6;
+    const double q0 = -(M[0] * u0 + M[1] * u1 + M[3] * u2);
+    const double q1 = -(M[2] * u1 + M[4] * u2);
+    const double q2 = -(M[5] * u2);
+    pp[(size_t)j * 3] = q0; pp[(size_t)j * 3 + 1] = q1; pp[(size_t)j * 3 + 2] = q2;
+    const double w0 = M[0] * q0, w1 = M[1] * q0 + M[2] * q1, w2 = M[3] * q0 + M[4] * q1 + M[5] * q2;
+    v[(size_t)j * 3] = w0; v[(size_t)j * 3 + 1] = w1; v[(size_t)j * 3 + 2] = w2;
+    p2 = q0 * q0 + q1 * q1 + q2 * q2;
+    v2 = w0 * w0 + w1 * w1 + w2 * w2;
+  }
+  double a = block_sum256(p2, s_red);
+  double b = block_sum256(v2, s_red);
+  if (threadIdx.x == 0) { part[blockIdx.x * 2] = a; part[blockIdx.x * 2 + 1] = b; }
+}
+
+// dst[0..cnt) = fixed-order sums of `cnt` interleaved partial columns (stride = cnt).
+__global__ __launch_bounds__(256) void k_sum_partials(const double* __restrict__ part, int nblk, int cnt,
+                                                      double* __restrict__ dst) {
+  __shared__ double s_red[4];
+  for (int q = 0; q < cnt; ++q) {
+    double t = 0.0;
+    for (int i = threadIdx.x; i < nblk; i += 256) t += part[(size_t)i * cnt + q];
+    double tt = block_sum256(t, s_red);
+    if (threadIdx.x == 0) dst[q] = tt;
+  }
+}
+
+// ------------------------------------------------------------------------------------ dense SPD: bordered Cholesky
+// A is [nrows][n] row-major, nrows = n (plain) or n+1 (last row = right-hand side, turned into L^-1 rhs).
+// Right-looking, panel width 32:  k_chol_panel factors the 32x32 diagonal block in ONE wavefront
+// (lane = row, the 32 columns in registers, pivots broadcast by v_readlane) - redundantly in every
+// workgroup - then solves its 256 rows of the panel by forward substitution from LDS;
+// k_chol_update applies the rank-32 update to the trailing lower tiles on v_mfma_f64_16x16x4_f64.
+__device__ __forceinline__ double readlane_d(double v, int l) {
+  int lo = __builtin_amdgcn_readlane(__double2loint(v), l);
+  int hi = __builtin_amdgcn_readlane(__double2hiint(v), l);
+  return __hiloint2double(hi, lo);
+}
+
+// Factor the 32x32 diagonal block in place: one wavefront, lane = row, the 32 columns in registers.
+__global__ __launch_bounds__(64) void k_chol_diag(double* __restrict__ A, int n, int j0, int* __restrict__ fail) {
+  const int i = threadIdx.x;
+  const int nb = (n - j0) < 32 ? (n - j0) : 32;
+  double a[32];
+#pragma unroll
+  for (int q = 0; q < 32; ++q)
+    a[q] = (i < nb && q < nb && q <= i) ? A[(size_t)(j0 + i) * n + j0 + q] : ((q == i) ? 1.0 : 0.0);
+  bool bad = false;
+#pragma unroll
+  for (int j = 0; j < 32; ++j) {
+    double piv = readlane_d(a[j], j);
+    if (!(piv > 0.0)) { bad = true; piv = 1.0; }
+    const double ljj = sqrt(piv);
+    if (i >= j) a[j] = a[j] / ljj;
+#pragma unroll
+    for (int q = j + 1; q < 32; ++q) {
+      const double lqj = readlane_d(a[j], q);
+      if (i >= q) a[q] -= a[j] * lqj;
+    }
+  }
+  if (i < nb) {
+#pragma unroll
+    for (int q = 0; q < 32; ++q)
+      if (q <= i && q < nb) A[(size_t)(j0 + i) * n + j0 + q] = a[q];
+  }
+  if (bad && i == 0) *fail = 1;
+}
+
+// Rows below the diagonal block: x L_jj^T = a by forward substitution, one thread per row, L_jj in LDS.
+__global__ __launch_bounds__(256) void k_chol_panel(double* __restrict__ A, int n, int nrows, int j0,
+                                                    double* __restrict__ panel) {
+  __shared__ double sL[32 * 33];
+  const int tid = threadIdx.x;
+  const int nb = (n - j0) < 32 ? (n - j0) : 32;
+  for (int i = tid; i < 32 * 32; i += 256) {
+    const int r = i >> 5, c = i & 31;
+    sL[r * 33 + c] = (r < nb && c <= r) ? A[(size_t)(j0 + r) * n + j0 + c] : ((r == c) ? 1.0 : 0.0);
+  }
+  __syncthreads();
+  const int j1 = j0 + nb;
+  const int i = j1 + blockIdx.x * 256 + tid;   // global row below the diagonal block
+  if (i >= nrows) return;
+  double x[32];
+  double* arow = A + (size_t)i * n + j0;
+#pragma unroll
+  for (int q = 0; q < 32; ++q) x[q] = (q < nb) ? arow[q] : 0.0;
+#pragma unroll
+  for (int q = 0; q < 32; ++q) {
+    const double xq = x[q] / sL[q * 33 + q];     // rows >= nb of sL are identity rows
+    x[q] = xq;
+#pragma unroll
+    for (int c = q + 1; c < 32; ++c) x[c] -= xq * sL[c * 33 + q];
+  }
+  double* prow = panel + (size_t)(i - j1) * 32;
+  // x[q] is exactly 0 for q >= nb (zero load, identity rows of sL).  The store into A is steered by an
+  // address select, not a branch: 32 predicated branches here made hipcc spill 600+ registers.
+#pragma unroll
+  for (int q = 0; q < 32; ++q) {
+    double* dst = (q < nb) ? (arow + q) : (prow + q);
+    *dst = x[q];
+    prow[q] = x[q];
+  }
+}
+
+__global__ __launch_bounds__(256) void k_chol_update(double* __restrict__ A, int n, int nrows, int j1,
+                                                     const double* __restrict__ panel) {
+  const int ti = blockIdx.y, tj = blockIdx.x;
+  if (tj > ti) return;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int rem_r = nrows - j1, rem_c = n - j1;
+  const int I0 = ti * 64 + w * 16, J0 = tj * 64;
+  if (I0 >= rem_r) return;
+  const int r16 = lane & 15, kq = lane >> 4;
+  v4d acc[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) acc[t] = (v4d){0.0, 0.0, 0.0, 0.0};
+  const int ar = I0 + r16;
+  const double* pa = panel + (size_t)ar * 32 + kq;
+  const bool va = ar < rem_r;
+#pragma unroll
+  for (int k0 = 0; k0 < 32; k0 += 4) {
+    const double a = va ? pa[k0] : 0.0;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const int br = J0 + t * 16 + r16;
+      const double b = (br < rem_c) ? panel[(size_t)br * 32 + k0 + kq] : 0.0;
+      acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[t], 0, 0, 0);
+    }
+  }
+  const int col16 = lane & 15;
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    const int gc_ = J0 + t * 16 + col16;
+    if (gc_ >= rem_c) continue;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int gr = I0 + (lane >> 4) + 4 * i;
+      if (gr < rem_r && gc_ <= gr) A[(size_t)(j1 + gr) * n + j1 + gc_] -= acc[t][i];
+    }
+  }
+}
+
+// Blocked triangular solves with the factor (block 64, one launch per block step).  In every launch
+// workgroup 0 first finishes the NEXT diagonal block (its own update, then the 64x64 solve in one
+// wavefront) so a step costs one kernel boundary.
+// transpose = 0:  L y = b (top-down);   transpose = 1:  L^T x = b (bottom-up).
+__global__ __launch_bounds__(256) void k_trsv_diag(const double* __restrict__ L, int n, double* __restrict__ b,
+                                                   int blk, int transpose) {
+  __shared__ double sD[64 * 65];
+  const int tid = threadIdx.x;
+  const int r0 = blk * 64;
+  const int nb = (n - r0) < 64 ? (n - r0) : 64;
+  for (int i = tid; i < 64 * 64; i += 256) {
+    const int r = i >> 6, c = i & 63;
+    sD[r * 65 + c] = (r < nb && c <= r) ? L[(size_t)(r0 + r) * n + r0 + c] : 0.0;
+  }
+  __syncthreads();
+  if (tid < 64) {
+    double y = (tid < nb) ? b[r0 + tid] : 0.0;
+    if (!transpose) {
+      for (int j = 0; j < nb; ++j) {
+        const double xj = readlane_d(y, j) / sD[j * 65 + j];
+        if (tid == j) y = xj;
+        else if (tid > j) y -= sD[tid * 65 + j] * xj;
+      }
+    } else {
+      for (int j = nb - 1; j >= 0; --j) {
+        const double xj = readlane_d(y, j) / sD[j * 65 + j];
+        if (tid == j) y = xj;
+        else if (tid < j) y -= sD[j * 65 + tid] * xj;
+      }
+    }
+    if (tid < nb) b[r0 + tid] = y;
+  }
+}
+
+// b[i] -= sum_{j in block} L[i][j] x_j  for rows i after the block (forward), or
+// b[i] -= sum_{j in block} L[j][i] x_j  for rows i before the block (transpose).
+__global__ __launch_bounds__(256) void k_trsv_update(const double* __restrict__ L, int n, double* __restrict__ b,
+                                                     int blk, int transpose) {
+  __shared__ double sx[64];
+  const int tid = threadIdx.x;
+  const int r0 = blk * 64;
+  const int nb = (n - r0) < 64 ? (n - r0) : 64;
+  if (tid < 64) sx[tid] = (tid < nb) ? b[r0 + tid] : 0.0;
+  __syncthreads();
+  if (!transpose) {
+    // one wavefront per row: lanes over the 64 columns of the block (coalesced), wave reduction
+    const int lane = tid & 63, w = tid >> 6;
+    const int i = r0 + nb + blockIdx.x * 4 + w;
+    if (i >= n) return;
+    double t = (lane < nb) ? L[(size_t)i * n + r0 + lane] * sx[lane] : 0.0;
+    t = wave_sum(t);
+    if (lane == 0) b[i] -= t;
+  } else {
+    const int i = blockIdx.x * 256 + tid;
+    if (i >= r0) return;
+    double t = 0.0;
+    for (int j = 0; j < nb; ++j) t += L[(size_t)(r0 + j) * n + i] * sx[j];
+    b[i] -= t;
+  }
+}
+
+static int dense_cholesky(sfm_ctx* h, double* A, int n, int nrows, double* panel, int* flag) {
+  for (int j0 = 0; j0 < n; j0 += 32) {
+    const int nb = (n - j0) < 32 ? (n - j0) : 32;
+    const int j1 = j0 + nb;
+    const int below = nrows - j1;
+    const unsigned g = below > 0 ? cdiv(below, 256) : 1;
+    hipLaunchKernelGGL(k_chol_diag, dim3(1), dim3(64), 0, h->stream, A, n, j0, flag);
+    if (below > 0) {
+      hipLaunchKernelGGL(k_chol_panel, dim3(g), dim3(256), 0, h->stream, A, n, nrows, j0, panel);
+      unsigned T = cdiv(below, 64);
+      hipLaunchKernelGGL(k_chol_update, dim3(T, T), dim3(256), 0, h->stream, A, n, nrows, j1, panel);
+    }
+  }
+  SFM_LAUNCH_CHECK(h, "dense_cholesky");
+  return SFM_OK;
+}
+
+static int dense_trsv(sfm_ctx* h, const double* L, int n, double* b, int transpose) {
+  const int nblk = (n + 63) / 64;
+  if (!transpose) {
+    for (int blk = 0; blk < nblk; ++blk) {
+      hipLaunchKernelGGL(k_trsv_diag, dim3(1), dim3(256), 0, h->stream, L, n, b, blk, 0);
+      const int after = n - (blk * 64 + 64);
+      if (after > 0)
+        hipLaunchKernelGGL(k_trsv_update, dim3(cdiv(after, 4)), dim3(256), 0, h->stream, L, n, b, blk, 0);
+    }
+  } else {
+    for (int blk = nblk - 1; blk >= 0; --blk) {
+      hipLaunchKernelGGL(k_trsv_diag, dim3(1), dim3(256), 0, h->stream, L, n, b, blk, 1);
+      const int before = blk * 64;
+      if (before > 0)
+        hipLaunchKernelGGL(k_trsv_update, dim3(cdiv(before, 256)), dim3(256), 0, h->stream, L, n, b, blk, 1);
+    }
+  }
+  SFM_LAUNCH_CHECK(h, "dense_trsv");
+  return SFM_OK;
+}
+
+__global__ void k_add_diag(double* __restrict__ A, int n, double alpha) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) A[(size_t)i * n + i] += alpha;
+}
+__global__ void k_copy_neg(const double* __restrict__ src, double* __restrict__ dst, int n, double sgn) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) dst[i] = sgn * src[i];
+}
+__global__ void k_add_vec(const double* __restrict__ a, const double* __restrict__ b, double* __restrict__ dst, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) dst[i] = a[i] + b[i];
+}
+
+// scalars after the solve: PNORM2 = ||p_c||^2 + sum ||p_p||^2 ; PQ = sum ||v||^2 + ||y||^2
+__global__ __launch_bounds__(256) void k_finish_solve(int n, const double* __restrict__ pc,
+                                                      const double* __restrict__ red_q,
+                                                      const double* __restrict__ y, int want_q,
+                                                      const int* __restrict__ flag, double* __restrict__ sc) {
+  __shared__ double s_red[4];
+  double a = 0.0, b = 0.0;
+  for (int i = threadIdx.x; i < n; i += 256) {
+    a += pc[i] * pc[i];
+    if (want_q) b += y[i] * y[i];
+  }
+  double at = block_sum256(a, s_red);
+  double bt = block_sum256(b, s_red);
+  if (threadIdx.x == 0) {
+    sc[SFM_SC_PNORM2] = at + red_q[n];
+    sc[SFM_SC_PQ] = want_q ? (bt + red_q[n + 1]) : 0.0;
+    sc[SFM_SC_CHOL_FAIL] = (double)(*flag);
+  }
+}
+
+// ------------------------------------------------------------------------------------ step + cost
+__global__ __launch_bounds__(256) void k_axpy_step(int64_t n_c, int64_t n_total, const double* __restrict__ x,
+                                                   const double* __restrict__ pc, const double* __restrict__ pp,
+                                                   double scale, double* __restrict__ x_new,
+                                                   double* __restrict__ part) {
+  __shared__ double s_red[4];
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  double s2 = 0.0, x2 = 0.0;
+  if (i < n_total) {
+    const bool is_cam = i < n_c;
+    const double s = scale * (is_cam ? pc[i] : pp[i - n_c]);
+    const double xn = x[i] + s;
+    x_new[i] = xn;
+    if (!is_cam) { s2 = s * s; x2 = xn * xn; }
+  }
+  double a = block_sum256(s2, s_red);
+  double b = block_sum256(x2, s_red);
+  if (threadIdx.x == 0) { part[blockIdx.x * 2] = a; part[blockIdx.x * 2 + 1] = b; }
+}
+
+// per observation: (J~ s) for both rows -> partial sums of (J~ s)^2 and f~ (J~ s)
+template <int D>
+__global__ __launch_bounds__(256) void k_step_obs(int64_t N, const int* __restrict__ cam_idx,
+                                                  const int* __restrict__ pt_idx,
+                                                  const double* __restrict__ rec,
+                                                  const double* __restrict__ pc, const double* __restrict__ pp,
+                                                  double scale, double* __restrict__ part) {
+  constexpr int REC = 2 * D + 8;
+  __shared__ double s_red[4];
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;   // (obs, row)
+  double j2 = 0.0, gt = 0.0;
+  if (i < 2 * N) {
+    const int64_t k = i >> 1;
+    const int row = (int)(i & 1);
+    const double* r = rec + (size_t)k * REC;
+    const double* jc = r + row * D;
+    const double* jp = r + 2 * D + row * 3;
+    const double* c = pc + (size_t)cam_idx[k] * D;
+    const double* q = pp + (size_t)pt_idx[k] * 3;
+    double t = jp[0] * q[0] + jp[1] * q[1] + jp[2] * q[2];
+#pragma unroll
+    for (int a = 0; a < D; ++a) t += jc[a] * c[a];
+    t *= scale;
+    j2 = t * t;
+    gt = r[2 * D + 6 + row] * t;
+  }
+  double a = block_sum256(j2, s_red);
+  double b = block_sum256(gt, s_red);
+  if (threadIdx.x == 0) { part[blockIdx.x * 4] = a; part[blockIdx.x * 4 + 1] = b; }
+}
+
+// Huber cost of the reprojection rows at the parameters behind `campre` / `pts`.
+__global__ __launch_bounds__(256) void k_cost_obs(int64_t N, const int* __restrict__ cam_idx,
+                                                  const int* __restrict__ pt_idx,
+                                                  const double* __restrict__ uv, const double* __restrict__ pts,
+                                                  const double* __restrict__ campre,
+                                                  double* __restrict__ part, int part_stride, int part_col,
+                                                  double* __restrict__ err_out) {
+  __shared__ double s_red[4];
+  const int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  double cost = 0.0;
+  if (k < N) {
+    const double* cp = campre + (size_t)cam_idx[k] * CAMPRE;
+    const size_t j = (size_t)pt_idx[k] * 3;
+    const double X0 = pts[j], X1 = pts[j + 1], X2 = pts[j + 2];
+    const double Y0 = cp[0] * X0 + cp[1] * X1 + cp[2] * X2 + cp[36];
+    const double Y1 = cp[3] * X0 + cp[4] * X1 + cp[5] * X2 + cp[37];
+    const double Y2 = cp[6] * X0 + cp[7] * X1 + cp[8] * X2 + cp[38];
+    const double iz = 1.0 / Y2;
+    const double f0 = cp[39] * (Y0 * iz) + cp[41] - uv[2 * k];
+    const double f1 = cp[40] * (Y1 * iz) + cp[42] - uv[2 * k + 1];
+    cost = 0.5 * (huber_rho0(f0) + huber_rho0(f1));
+    if (err_out) err_out[k] = sqrt(f0 * f0 + f1 * f1);
+  }
+  double t = block_sum256(cost, s_red);
+  if (threadIdx.x == 0 && part) part[(size_t)blockIdx.x * part_stride + part_col] = t;
+}
+
+// regulariser rows at x_new (cost) and their share of J~ s, f~ J~ s
+__global__ void k_reg_step(int C, const double* __restrict__ cams_new, const double* __restrict__ pc,
+                           double scale, const double* __restrict__ regrec, double fx0, double cx0, double cy0,
+                           double width, double height, double w, int with_lin,
+                           double* __restrict__ cost_reg /*[C][4]: cost, js2, gts*/) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const double* p = cams_new + (size_t)c * 10;
+  const double fx = p[6], fy = p[7], cx = p[8], cy = p[9];
+  const double f[4] = {(fx - fx0) / fx0 * w, (fy - fx) / fx * w, (cx - cx0) / width * w, (cy - cy0) / height * w};
+  double cost = 0.0;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) cost += huber_rho0(f[r]);
+  double js2 = 0.0, gts = 0.0;
+  if (with_lin) {
+    const double* rr = regrec + (size_t)c * 20;
+    const double* s = pc + (size_t)c * 10 + 6;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const double t = scale * (rr[r * 4] * s[0] + rr[r * 4 + 1] * s[1] + rr[r * 4 + 2] * s[2] + rr[r * 4 + 3] * s[3]);
+      js2 += t * t;
+      gts += rr[16 + r] * t;
+    }
+  }
+  cost_reg[(size_t)c * 4] = 0.5 * cost;
+  cost_reg[(size_t)c * 4 + 1] = js2;
+  cost_reg[(size_t)c * 4 + 2] = gts;
+}
+
+// red_step = [ js2, gts, cost_new, s_pts2, xnew_pts2 ] (this rank's partial sums, fixed order)
+__global__ __launch_bounds__(256) void k_step_finalize(const double* __restrict__ part_obs, int nblk_obs,
+                                                       int nblk_rows, const double* __restrict__ part_x, int nblk_x,
+                                                       const double* __restrict__ cost_reg, int n_reg,
+                                                       int with_lin, double* __restrict__ red_step) {
+  __shared__ double s_red[4];
+  double v[5] = {0, 0, 0, 0, 0};
+  for (int i = threadIdx.x; i < nblk_obs; i += 256) v[2] += part_obs[(size_t)i * 4 + 2];
+  if (with_lin)
+    for (int i = threadIdx.x; i < nblk_rows; i += 256) { v[0] += part_obs[(size_t)i * 4]; v[1] += part_obs[(size_t)i * 4 + 1]; }
+  for (int i = threadIdx.x; i < n_reg; i += 256) {
+    v[2] += cost_reg[(size_t)i * 4]; v[0] += cost_reg[(size_t)i * 4 + 1]; v[1] += cost_reg[(size_t)i * 4 + 2];
+  }
+  if (with_lin)
+    for (int i = threadIdx.x; i < nblk_x; i += 256) { v[3] += part_x[(size_t)i * 2]; v[4] += part_x[(size_t)i * 2 + 1]; }
+#pragma unroll
+  for (int q = 0; q < 5; ++q) {
+    double t = block_sum256(v[q], s_red);
+    if (threadIdx.x == 0) red_step[q] = t;
+  }
+}
+
+__global__ __launch_bounds__(256) void k_finish_step(int n_c, const double* __restrict__ pc, double scale,
+                                                     const double* __restrict__ x_new,
+                                                     const double* __restrict__ red_step,
+                                                     double* __restrict__ sc) {
+  __shared__ double s_red[4];
+  double s2 = 0.0, x2 = 0.0;
+  for (int i = threadIdx.x; i < n_c; i += 256) {
+    const double s = scale * pc[i];
+    s2 += s * s;
+    x2 += x_new[i] * x_new[i];
+  }
+  double a = block_sum256(s2, s_red);
+  double b = block_sum256(x2, s_red);
+  if (threadIdx.x == 0) {
+    sc[SFM_SC_JS2] = red_step[0]; sc[SFM_SC_GTS] = red_step[1]; sc[SFM_SC_COST_NEW] = red_step[2];
+    sc[SFM_SC_SNORM2] = a + red_step[3]; sc[SFM_SC_XNEW_NORM2] = b + red_step[4];
+  }
+}
+
+// ------------------------------------------------------------------------------------ host stages
+static int check_problem(sfm_ctx* h, const sfm_ba_problem* p, Lay* L) {
+  if (!h) return SFM_ERR_ARG;
+  if (!p || p->n_cams < 1 || p->n_pts < 1 || p->n_obs < 1 || (p->cam_dim != 6 && p->cam_dim != 10))
+    return sfm_fail(h, SFM_ERR_ARG, "sfm_ba", "bad problem sizes / cam_dim");
+  if (!p->cam_idx || !p->pt_idx || !p->uv || !p->pt_ptr || !p->cam_ptr || !p->cam_obs || !p->blk_ptr ||
+      (p->n_pairs > 0 && (!p->pair_k || !p->pair_k2)) || !p->workspace)
+    return sfm_fail(h, SFM_ERR_ARG, "sfm_ba", "null pointer in problem");
+  if ((int64_t)p->n_cams * p->cam_dim > 32000) return sfm_fail(h, SFM_ERR_ARG, "sfm_ba", "reduced system too large");
+  *L = ba_layout(p->n_cams, p->n_pts, p->n_obs, p->cam_dim);
+  if (p->workspace_bytes < L->total * 8) return sfm_fail(h, SFM_ERR_WORKSPACE, "sfm_ba", "workspace too small");
+  return SFM_OK;
+}
+
+#define WS(L, field) (ws + (L).field)
+#define DISPATCH_D(D, ...)            \
+  do {                                \
+    if ((D) == 10) { constexpr int DD = 10; __VA_ARGS__; } \
+    else { constexpr int DD = 6; __VA_ARGS__; }            \
+  } while (0)
+
+static int launch_cost(sfm_ctx* h, const sfm_ba_problem* p, const Lay& L, double* ws, const double* x,
+                       const double* pc_for_reg, double scale, int with_lin, double* err_out) {
+  const int C = p->n_cams, D = p->cam_dim;
+  const int64_t N = p->n_obs;
+  const double* cams = x;
+  const double* pts = x + (size_t)C * D;
+  DISPATCH_D(D, hipLaunchKernelGGL(k_campre<DD>, dim3(cdiv(C, 64)), dim3(64), 0, h->stream, cams, C, p->fx0,
+                                   p->fy0, p->cx0, p->cy0, WS(L, campre2)));
+  hipLaunchKernelGGL(k_cost_obs, dim3((unsigned)L.nblk_obs), dim3(256), 0, h->stream, N, p->cam_idx, p->pt_idx,
+                     p->uv, pts, WS(L, campre2), WS(L, part_obs), 4, 2, err_out);
+  if (D == 10 && p->apply_reg)
+    hipLaunchKernelGGL(k_reg_step, dim3(cdiv(C, 64)), dim3(64), 0, h->stream, C, cams, pc_for_reg, scale,
+                       WS(L, regrec), p->fx0, p->cx0, p->cy0, p->width, p->height, p->reg_weight, with_lin,
+                       WS(L, cost_reg));
+  SFM_LAUNCH_CHECK(h, "launch_cost");
+  return SFM_OK;
+}
+
+extern "C" int sfm_ba_cost(sfm_handle h, const sfm_ba_problem* p, const double* x) {
+  Lay L; int rc = check_problem(h, p, &L); if (rc) return rc;
+  double* ws = (double*)p->workspace;
+  rc = launch_cost(h, p, L, ws, x, nullptr, 0.0, 0, nullptr); if (rc) return rc;
+  const int nreg = (p->cam_dim == 10 && p->apply_reg) ? p->n_cams : 0;
+  hipLaunchKernelGGL(k_step_finalize, dim3(1), dim3(256), 0, h->stream, WS(L, part_obs), (int)L.nblk_obs, 0,
+                     (const double*)nullptr, 0, WS(L, cost_reg), nreg, 0, WS(L, red_step));
+  SFM_LAUNCH_CHECK(h, "sfm_ba_cost");
+  return SFM_OK;
+}
+
+__global__ void k_set_intrinsics(int C, double fx, double fy, double cx, double cy, double* __restrict__ cp) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  double* o = cp + (size_t)c * CAMPRE;
+  o[39] = fx; o[40] = fy; o[41] = cx; o[42] = cy;
+}
+
+extern "C" int sfm_ba_reproj_errors(sfm_handle h, const sfm_ba_problem* p, const double* x, int shared_k,
+                                    double* err_out) {
+  Lay L; int rc = check_problem(h, p, &L); if (rc) return rc;
+  if (!err_out) return sfm_fail(h, SFM_ERR_ARG, "sfm_ba_reproj_errors", "null output");
+  double* ws = (double*)p->workspace;
+  const int C = p->n_cams, D = p->cam_dim;
+  DISPATCH_D(D, hipLaunchKernelGGL(k_campre<DD>, dim3(cdiv(C, 64)), dim3(64), 0, h->stream, x, C, p->fx0,
+                                   p->fy0, p->cx0, p->cy0, WS(L, campre2)));
+  // compute_reconstruction_stats projects with the ONE shared self.K (sfm_reconstruction.py:601)
+  if (shared_k)
+    hipLaunchKernelGGL(k_set_intrinsics, dim3(cdiv(C, 64)), dim3(64), 0, h->stream, C, p->fx0, p->fy0, p->cx0,
+                       p->cy0, WS(L, campre2));
+  hipLaunchKernelGGL(k_cost_obs, dim3((unsigned)L.nblk_obs), dim3(256), 0, h->stream, p->n_obs, p->cam_idx,
+                     p->pt_idx, p->uv, x + (size_t)C * D, WS(L, campre2), (double*)nullptr, 0, 0, err_out);
+  SFM_LAUNCH_CHECK(h, "sfm_ba_reproj_errors");
+  return SFM_OK;
+}
+
+extern "C" int sfm_ba_linearize(sfm_handle h, const sfm_ba_problem* p, const double* x) {
+  Lay L; int rc = check_problem(h, p, &L); if (rc) return rc;
+  double* ws = (double*)p->workspace;
+  const int C = p->n_cams, P = p->n_pts, D = p->cam_dim, n = C * D;
+  const int64_t N = p->n_obs;
+  const double* pts = x + (size_t)n;
+  DISPATCH_D(D, {
+    hipLaunchKernelGGL(k_campre<DD>, dim3(cdiv(C, 64)), dim3(64), 0, h->stream, x, C, p->fx0, p->fy0, p->cx0,
+                       p->cy0, WS(L, campre));
+    hipLaunchKernelGGL(k_lin_obs<DD>, dim3((unsigned)L.nblk_obs), dim3(256), 0, h->stream, N, p->cam_idx,
+                       p->pt_idx, p->uv, pts, WS(L, campre), WS(L, rec), WS(L, part_obs));
+    hipLaunchKernelGGL(k_point_blocks<DD>, dim3((unsigned)L.nblk_pt), dim3(256), 0, h->stream, P, p->pt_ptr,
+                       WS(L, rec), WS(L, Cp), WS(L, gp), WS(L, part_pt));
+    hipLaunchKernelGGL(k_cam_blocks<DD>, dim3(C), dim3(256), 0, h->stream, p->cam_ptr, p->cam_obs, WS(L, rec),
+                       WS(L, B), WS(L, gc));
+  });
+  int nreg = 0;
+  if (D == 10 && p->apply_reg) {
+    nreg = C;
+    hipLaunchKernelGGL(k_cam_reg, dim3(cdiv(C, 64)), dim3(64), 0, h->stream, C, x, p->fx0, p->cx0, p->cy0,
+                       p->width, p->height, p->reg_weight, WS(L, B), WS(L, gc), WS(L, cost_reg), WS(L, regrec));
+  }
+  // cost_reg is [C][4] in the step stage and [C] here: use stride 1 in both by writing column 0 only
+  hipLaunchKernelGGL(k_lin_finalize, dim3(1), dim3(256), 0, h->stream, n, WS(L, gc), WS(L, part_obs),
+                     (int)L.nblk_obs, WS(L, part_pt), (int)L.nblk_pt, WS(L, cost_reg), nreg, WS(L, red_lin),
+                     WS(L, gmax));
+  SFM_LAUNCH_CHECK(h, "sfm_ba_linearize");
+  return SFM_OK;
+}
+
+extern "C" int sfm_ba_finish_linearize(sfm_handle h, const sfm_ba_problem* p) {
+  Lay L; int rc = check_problem(h, p, &L); if (rc) return rc;
+  double* ws = (double*)p->workspace;
+  hipLaunchKernelGGL(k_finish_linearize, dim3(1), dim3(256), 0, h->stream, p->n_cams * p->cam_dim,
+                     WS(L, red_lin), WS(L, gmax), WS(L, scalars));
+  SFM_LAUNCH_CHECK(h, "sfm_ba_finish_linearize");
+  return SFM_OK;
+}
+
+extern "C" int sfm_ba_schur_build(sfm_handle h, const sfm_ba_problem* p, double alpha) {
+  Lay L; int rc = check_problem(h, p, &L); if (rc) return rc;
+  if (!(alpha > 0.0)) return sfm_fail(h, SFM_ERR_ARG, "sfm_ba_schur_build", "alpha must be > 0");
+  double* ws = (double*)p->workspace;
+  const int C = p->n_cams, P = p->n_pts, D = p->cam_dim, n = C * D;
+  const int64_t N = p->n_obs;
+  hipLaunchKernelGGL(k_point_factor, dim3(cdiv(P, 256)), dim3(256), 0, h->stream, P, alpha, WS(L, Cp), WS(L, gp),
+                     WS(L, Linv), WS(L, e));
+  DISPATCH_D(D, {
+    const int64_t tot = N * 3 * DD;
+    hipLaunchKernelGGL(k_build_G<DD>, dim3(cdiv(tot, 256)), dim3(256), 0, h->stream, tot, p->pt_idx, WS(L, rec),
+                       WS(L, Linv), WS(L, G));
+    hipLaunchKernelGGL(k_schur_blocks<DD>, dim3(C, cdiv(C, 4)), dim3(256), 0, h->stream, C, p->blk_ptr,
+                       p->pair_k, p->pair_k2, WS(L, G), WS(L, B), WS(L, red_S));
+    hipLaunchKernelGGL(k_cam_reduce<DD>, dim3(C), dim3(256), 0, h->stream, p->cam_ptr, p->cam_obs, p->pt_idx,
+                       WS(L, G), WS(L, e), WS(L, gc), WS(L, red_S) + (size_t)n * n);
+  });
+  SFM_LAUNCH_CHECK(h, "sfm_ba_schur_build");
+  return SFM_OK;
+}
+
+extern "C" int sfm_ba_schur_solve(sfm_handle h, const sfm_ba_problem* p, double alpha, int want_q) {
+  Lay L; int rc = check_problem(h, p, &L); if (rc) return rc;
+  double* ws = (double*)p->workspace;
+  const int C = p->n_cams, P = p->n_pts, D = p->cam_dim, n = C * D;
+  const int64_t N = p->n_obs;
+  double* S = WS(L, red_S);
+  int* flag = (int*)WS(L, flag);
+  SFM_HIP(h, hipMemsetAsync(flag, 0, sizeof(int), h->stream));
+  hipLaunchKernelGGL(k_add_diag, dim3(cdiv(n, 256)), dim3(256), 0, h->stream, S, n, alpha);
+  rc = dense_cholesky(h, S, n, n + 1, WS(L, panel), flag); if (rc) return rc;   // row n: r -> L^-1 r
+  // p_c = -L^-T (L^-1 r)
+  hipLaunchKernelGGL(k_copy_neg, dim3(cdiv(n, 256)), dim3(256), 0, h->stream, S + (size_t)n * n, WS(L, pc), n, -1.0);
+  rc = dense_trsv(h, S, n, WS(L, pc), 1); if (rc) return rc;
+  DISPATCH_D(D, hipLaunchKernelGGL(k_obs_Gtp<DD>, dim3(cdiv(N * 3, 256)), dim3(256), 0, h->stream, N * 3,
+                                   p->cam_idx, WS(L, G), WS(L, pc), WS(L, tmp3)));
+  hipLaunchKernelGGL(k_backsub, dim3((unsigned)L.nblk_pt), dim3(256), 0, h->stream, P, p->pt_ptr, WS(L, tmp3),
+                     WS(L, Linv), WS(L, e), WS(L, pp), WS(L, v), WS(L, part_pt));
+  hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(256), 0, h->stream, WS(L, part_pt), (int)L.nblk_pt, 2,
+                     WS(L, red_q) + n);
+  if (want_q) {
+    DISPATCH_D(D, hipLaunchKernelGGL(k_cam_reduce<DD>, dim3(C), dim3(256), 0, h->stream, p->cam_ptr, p->cam_obs,
+                                     p->pt_idx, WS(L, G), WS(L, v), (const double*)nullptr, WS(L, red_q)));
+  }
+  SFM_LAUNCH_CHECK(h, "sfm_ba_schur_solve");
+  return SFM_OK;
+}
+
+extern "C" int sfm_ba_finish_solve(sfm_handle h, const sfm_ba_problem* p, int want_q) {
+  Lay L; int rc = check_problem(h, p, &L); if (rc) return rc;
+  double* ws = (double*)p->workspace;
+  const int n = p->n_cams * p->cam_dim;
+  if (want_q) {
+    // rhs2 = p_c - W C_a^-1 p_p ;  y = L^-1 rhs2
+    hipLaunchKernelGGL(k_add_vec, dim3(cdiv(n, 256)), dim3(256), 0, h->stream, WS(L, pc), WS(L, red_q), WS(L, y), n);
+    rc = dense_trsv(h, WS(L, red_S), n, WS(L, y), 0); if (rc) return rc;
+  }
+  hipLaunchKernelGGL(k_finish_solve, dim3(1), dim3(256), 0, h->stream, n, WS(L, pc), WS(L, red_q), WS(L, y),
+                     want_q, (const int*)WS(L, flag), WS(L, scalars));
+  SFM_LAUNCH_CHECK(h, "sfm_ba_finish_solve");
+  return SFM_OK;
+}
+
+extern "C" int sfm_ba_step(sfm_handle h, const sfm_ba_problem* p, const double* x, double scale, double* x_new) {
+  Lay L; int rc = check_problem(h, p, &L); if (rc) return rc;
+  double* ws = (double*)p->workspace;
+  const int C = p->n_cams, P = p->n_pts, D = p->cam_dim, n = C * D;
+  const int64_t N = p->n_obs, ntot = (int64_t)n + 3 * (int64_t)P;
+  double* part_x = WS(L, part_x);
+  const unsigned nblk_x = cdiv(ntot, 256), nblk_rows = cdiv(2 * N, 256);
+  hipLaunchKernelGGL(k_axpy_step, dim3(nblk_x), dim3(256), 0, h->stream, (int64_t)n, ntot, x, WS(L, pc), WS(L, pp),
+                     scale, x_new, part_x);
+  DISPATCH_D(D, hipLaunchKernelGGL(k_step_obs<DD>, dim3(nblk_rows), dim3(256), 0, h->stream, N, p->cam_idx,
+                                   p->pt_idx, WS(L, rec), WS(L, pc), WS(L, pp), scale, WS(L, part_obs)));
+  rc = launch_cost(h, p, L, ws, x_new, WS(L, pc), scale, 1, nullptr); if (rc) return rc;
+  const int nreg = (D == 10 && p->apply_reg) ? C : 0;
+  hipLaunchKernelGGL(k_step_finalize, dim3(1), dim3(256), 0, h->stream, WS(L, part_obs), (int)L.nblk_obs,
+                     (int)nblk_rows, part_x, (int)nblk_x, WS(L, cost_reg), nreg, 1, WS(L, red_step));
+  SFM_LAUNCH_CHECK(h, "sfm_ba_step");
+  return SFM_OK;
+}
+
+extern "C" int sfm_ba_finish_step(sfm_handle h, const sfm_ba_problem* p, const double* x, double scale,
+                                  const double* x_new) {
+  Lay L; int rc = check_problem(h, p, &L); if (rc) return rc;
+  double* ws = (double*)p->workspace;
+  (void)x;
+  hipLaunchKernelGGL(k_finish_step, dim3(1), dim3(256), 0, h->stream, p->n_cams * p->cam_dim, WS(L, pc), scale,
+                     x_new, WS(L, red_step), WS(L, scalars));
+  SFM_LAUNCH_CHECK(h, "sfm_ba_finish_step");
+  return SFM_OK;
+}
+
+extern "C" int sfm_ba_read_scalars(sfm_handle h, const sfm_ba_problem* p, double* out_host) {
+  Lay L; int rc = check_problem(h, p, &L); if (rc) return rc;
+  double* ws = (double*)p->workspace;
+  SFM_HIP(h, hipMemcpyAsync(h->pinned, WS(L, scalars), SFM_SC_COUNT * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  SFM_HIP(h, hipStreamSynchronize(h->stream));
+  memcpy(out_host, h->pinned, SFM_SC_COUNT * sizeof(double));
+  return SFM_OK;
+}
+
+// ------------------------------------------------------------------------------------ exported dense helpers
+extern "C" int sfm_dense_cholesky(sfm_handle h, double* a, int32_t n, int32_t* fail_flag) {
+  if (!h || !a || n < 1 || !fail_flag) return SFM_ERR_ARG;
+  double* panel = nullptr;
+  SFM_HIP(h, hipMalloc(&panel, (size_t)(n + 1) * 32 * sizeof(double)));
+  SFM_HIP(h, hipMemsetAsync(fail_flag, 0, sizeof(int), h->stream));
+  int rc = dense_cholesky(h, a, n, n, panel, fail_flag);
+  SFM_HIP(h, hipStreamSynchronize(h->stream));
+  SFM_HIP(h, hipFree(panel));
+  return rc;
+}
+
+extern "C" int sfm_dense_trsv(sfm_handle h, const double* l, int32_t n, double* b, int transpose) {
+  if (!h || !l || !b || n < 1) return SFM_ERR_ARG;
+  return dense_trsv(h, l, n, b, transpose ? 1 : 0);
+}

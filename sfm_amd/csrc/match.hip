@@ -1,0 +1,420 @@
+// Brute-force kNN (k=2) + Lowe ratio test for gfx950 (MI355X).
+//
+// Replaces cv2.BFMatcher.knnMatch(desc1, desc2, k=2) and the ratio loop of
+// ImageMatcher.match_features (/root/reference/utils/find_matches.py:141-155).
+//
+// L2 on uint8 descriptors (SIFT, dim 32/64/128) is exact integer arithmetic on the matrix cores:
+//   a = x - 128 (= x ^ 0x80), c = 127 - y (= y ^ 0x7F) are int8, and
+//   d^2 = sum (x-y)^2 = sum (a + c + 1)^2 = TN_i + QN_j + 2 * dot(a_i, c_j),
+//   TN_i = sum (a+1)^2 - dim,  QN_j = sum (c+1)^2           (all int32, d^2 <= 128*255^2 < 2^23)
+// with dot() from v_mfma_i32_32x32x32_i8 (A = 32 train rows, B = 32 queries: the accumulator puts
+// the query on the lane and 16 train rows in the registers, so the running top-2 of a query never
+// leaves its lane).  Candidates are ranked by ONE int32 key = ((TN_i + 2 dot) << 8) | row-in-chunk,
+// i.e. v_lshl_add_u32 + v_min_i32 + v_med3_i32 per candidate; keys are unpacked every 128 train rows.
+// Ties go to the lower train index (OpenCV's documented order); sqrtf is applied once at the end.
+#include "common.h"
+
+typedef int v4i __attribute__((ext_vector_type(4)));
+typedef int v16i __attribute__((ext_vector_type(16)));
+
+#define KEY_SENTINEL 0x7FFFFF00
+#define D2_MAX_VALID 8323200   // 128 * 255^2
+
+struct Cand { float d; int i; };   // distance (already sqrtf'ed / popcount), train index; i < 0 = empty
+
+__device__ __forceinline__ bool cand_less(float d, int i, float d2, int i2) {
+  return (d < d2) || (d == d2 && (unsigned)i < (unsigned)i2);   // i = -1 (empty) sorts last
+}
+__device__ __forceinline__ void top2_insert(float d, int i, float& b1d, int& b1i, float& b2d, int& b2i) {
+  if (i < 0) return;
+  if (cand_less(d, i, b1d, b1i)) { b2d = b1d; b2i = b1i; b1d = d; b1i = i; }
+  else if (cand_less(d, i, b2d, b2i)) { b2d = d; b2i = i; }
+}
+
+// ------------------------------------------------------------------------------------ row norms (uint8)
+// out[i] = sum (v+1)^2 - sub over the row, v = (byte ^ flip) as int8.  train: flip 0x80, sub = dim;
+// query: flip 0x7F, sub = 0.
+__global__ __launch_bounds__(256) void k_row_norm_u8(const uint8_t* __restrict__ x, int64_t n, int dim, int flip,
+                                                     int sub, int* __restrict__ out) {
+  const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (r >= n) return;
+  const uint8_t* p = x + r * dim;
+  int s = 0;
+  for (int k = 0; k < dim; ++k) {
+    const int v = (int)(int8_t)(p[k] ^ flip) + 1;
+    s += v * v;
+  }
+  out[r] = s - sub;
+}
+
+// ------------------------------------------------------------------------------------ L2 / uint8 on i8 MFMA
+// grid.x = n_qblocks * nsplit: split = blockIdx.x % nsplit so that, with the round-robin XCD placement,
+// the workgroups streaming one train split share an XCD's L2 (speed only).  256 threads = 4 waves,
+// each wave owns QB blocks of 32 queries; the train split is streamed through LDS in chunks of 128 rows
+// (XOR-swizzled 16-byte granules: conflict-free ds_read_b128), double buffered.
+template <int KS, int QB>   // KS = dim / 32
+__global__ __launch_bounds__(256) void k_knn2_u8(const uint8_t* __restrict__ q, int64_t nq,
+                                                 const uint8_t* __restrict__ t, int64_t nt,
+                                                 const int* __restrict__ tn, const int* __restrict__ qn,
+                                                 int nsplit, int64_t rows_per_split, Cand* __restrict__ part) {
+  constexpr int DIM = KS * 32;
+  constexpr int GPR = DIM / 16;                 // 16-byte granules per row
+  constexpr int CHUNK = 128;                   // rows per LDS chunk (2 x 16 KiB at dim 128)
+  constexpr int GPT = CHUNK * GPR / 256;        // granules staged per thread
+  __shared__ uint4 s_t[2][CHUNK * GPR];
+  __shared__ int s_k0[2][CHUNK];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, half = lane >> 5, l31 = lane & 31;
+  const int split = blockIdx.x % nsplit;
+  const int64_t qblock = blockIdx.x / nsplit;
+  const int64_t t_beg = (int64_t)split * rows_per_split;
+  const int64_t t_end = (t_beg + rows_per_split) < nt ? (t_beg + rows_per_split) : nt;
+  const int64_t q0 = qblock * (4 * QB * 32) + (int64_t)w * (QB * 32);
+
+  // query fragments: lane holds bytes [32 ks + 16 half, +16) of query q0 + 32 qb + l31
+  v4i bq[QB][KS];
+  int qnv[QB];
+#pragma unroll
+  for (int qb = 0; qb < QB; ++qb) {
+    const int64_t qi = q0 + qb * 32 + l31;
+    const bool ok = qi < nq;
+    qnv[qb] = ok ? qn[qi] : 0;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      v4i v = {0, 0, 0, 0};
+      if (ok) v = *(const v4i*)(q + qi * DIM + ks * 32 + half * 16);
+      bq[qb][ks] = v ^ 0x7F7F7F7F;
+    }
+  }
+  float g1d[QB], g2d[QB];
+  int g1i[QB], g2i[QB];
+  int g1k[QB], g2k[QB];   // exact integer d^2 of the running best two
+#pragma unroll
+  for (int qb = 0; qb < QB; ++qb) { g1k[qb] = 0x7FFFFFFF; g2k[qb] = 0x7FFFFFFF; g1i[qb] = -1; g2i[qb] = -1; }
+
+  const int64_t n_rows = t_end > t_beg ? (t_end - t_beg) : 0;
+  const int n_chunks = (int)((n_rows + CHUNK - 1) / CHUNK);
+
+  uint4 stage[GPT];
+  int stage_k0 = 0;
+  auto load_chunk = [&](int ch) {
+    const int64_t base = t_beg + (int64_t)ch * CHUNK;
+#pragma unroll
+    for (int i = 0; i < GPT; ++i) {
+      const int g = tid + 256 * i;
+      const int row = g / GPR, slot = g % GPR;
+      const int64_t tr = base + row;
+      uint4 v = make_uint4(0x80808080u, 0x80808080u, 0x80808080u, 0x80808080u);   // -> 0 after the flip
+      if (tr < t_end) v = *(const uint4*)(t + tr * DIM + slot * 16);
+      stage[i] = v;
+    }
+    if (tid < CHUNK) {
+      const int64_t tr = base + tid;
+      stage_k0 = (tr < t_end) ? ((tn[tr] << 8) | tid) : (KEY_SENTINEL | tid);
+    }
+  };
+  auto store_chunk = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < GPT; ++i) {
+      const int g = tid + 256 * i;
+      const int row = g / GPR, slot = g % GPR;
+      const int sw = (slot ^ ((row >> 1) & (GPR - 1)));
+      uint4 v = stage[i];
+      v.x ^= 0x80808080u; v.y ^= 0x80808080u; v.z ^= 0x80808080u; v.w ^= 0x80808080u;
+      s_t[buf][row * GPR + sw] = v;
+    }
+    if (tid < CHUNK) s_k0[buf][tid] = stage_k0;
+  };
+
+  if (n_chunks > 0) { load_chunk(0); store_chunk(0); }
+  __syncthreads();
+  for (int ch = 0; ch < n_chunks; ++ch) {
+    const int buf = ch & 1;
+    if (ch + 1 < n_chunks) load_chunk(ch + 1);
+    int m1[QB], m2[QB];
+#pragma unroll
+    for (int qb = 0; qb < QB; ++qb) { m1[qb] = 0x7FFFFFFF; m2[qb] = 0x7FFFFFFF; }
+#pragma unroll 2
+    for (int tile = 0; tile < CHUNK / 32; ++tile) {
+      const int row = tile * 32 + l31;
+      v4i at[KS];
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        const int slot = ks * 2 + half;
+        const int sw = (slot ^ ((row >> 1) & (GPR - 1)));
+        const uint4 v = s_t[buf][row * GPR + sw];
+        at[ks] = (v4i){(int)v.x, (int)v.y, (int)v.z, (int)v.w};
+      }
+      // K0 of the 16 train rows this lane's accumulator registers hold: rows (r&3) + 8 (r>>2) + 4 half
+      int k0[16];
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int4 kk = *(const int4*)&s_k0[buf][tile * 32 + 8 * g + 4 * half];
+        k0[4 * g] = kk.x; k0[4 * g + 1] = kk.y; k0[4 * g + 2] = kk.z; k0[4 * g + 3] = kk.w;
+      }
+#pragma unroll
+      for (int qb = 0; qb < QB; ++qb) {
+        v16i acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(at[ks], bq[qb][ks], acc, 0, 0, 0);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int key = (acc[r] << 9) + k0[r];
+          int nm2;
+          asm("v_med3_i32 %0, %1, %2, %3" : "=v"(nm2) : "v"(m1[qb]), "v"(m2[qb]), "v"(key));
+          m2[qb] = nm2;
+          m1[qb] = min(m1[qb], key);
+        }
+      }
+    }
+    // unpack this chunk's best two and merge into the running pair (later chunks = higher indices,
+    // so strict '<' keeps the lower index on equal d^2)
+    const int cbase = (int)(t_beg + (int64_t)ch * CHUNK);
+#pragma unroll
+    for (int qb = 0; qb < QB; ++qb) {
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        const int m = s == 0 ? m1[qb] : m2[qb];
+        if ((m | 0xFF) == (KEY_SENTINEL | 0xFF) || m == 0x7FFFFFFF) continue;
+        const int d2 = (m >> 8) + qnv[qb];
+        const int idx = cbase + (m & 0xFF);
+        if (d2 < g1k[qb]) { g2k[qb] = g1k[qb]; g2i[qb] = g1i[qb]; g1k[qb] = d2; g1i[qb] = idx; }
+        else if (d2 < g2k[qb]) { g2k[qb] = d2; g2i[qb] = idx; }
+      }
+    }
+    if (ch + 1 < n_chunks) store_chunk(buf ^ 1);
+    __syncthreads();
+  }
+  // the two halves of the wave hold the same query with disjoint train rows: merge, lower index on ties
+#pragma unroll
+  for (int qb = 0; qb < QB; ++qb) {
+    const int o1k = __shfl_xor(g1k[qb], 32, 64), o1i = __shfl_xor(g1i[qb], 32, 64);
+    const int o2k = __shfl_xor(g2k[qb], 32, 64), o2i = __shfl_xor(g2i[qb], 32, 64);
+    g1d[qb] = (float)g1k[qb]; g2d[qb] = (float)g2k[qb];      // exact: d^2 < 2^24
+    float b1d = 3.0e38f, b2d = 3.0e38f; int b1i = -1, b2i = -1;
+    top2_insert(g1d[qb], g1i[qb], b1d, b1i, b2d, b2i);
+    top2_insert(g2d[qb], g2i[qb], b1d, b1i, b2d, b2i);
+    top2_insert((float)o1k, o1i, b1d, b1i, b2d, b2i);
+    top2_insert((float)o2k, o2i, b1d, b1i, b2d, b2i);
+    const int64_t qi = q0 + qb * 32 + l31;
+    if (half == 0 && qi < nq) {
+      Cand* o = part + ((int64_t)split * nq + qi) * 2;
+      o[0].d = b1i >= 0 ? __fsqrt_rn(b1d) : 0.0f; o[0].i = b1i;
+      o[1].d = b2i >= 0 ? __fsqrt_rn(b2d) : 0.0f; o[1].i = b2i;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------ generic VALU kernel
+// METRIC 1: float32, d^2 accumulated over k ascending with separately rounded multiply and add (the
+// oracle's stated order), distance = sqrtf(d^2).  METRIC 2: Hamming popcount over dim bytes (dim % 4 == 0).
+// One thread = one query (held in registers), train rows broadcast from LDS, 64-row tiles.
+template <int METRIC, int DIMW>   // DIMW = 32-bit words per row
+__global__ __launch_bounds__(256) void k_knn2_valu(const uint32_t* __restrict__ q, int64_t nq,
+                                                   const uint32_t* __restrict__ t, int64_t nt, int nsplit,
+                                                   int64_t rows_per_split, Cand* __restrict__ part) {
+  constexpr int TILE = 32;
+  __shared__ uint32_t s_t[TILE * DIMW];
+  const int tid = threadIdx.x;
+  const int split = blockIdx.x % nsplit;
+  const int64_t qi = (int64_t)(blockIdx.x / nsplit) * 256 + tid;
+  const int64_t t_beg = (int64_t)split * rows_per_split;
+  const int64_t t_end = (t_beg + rows_per_split) < nt ? (t_beg + rows_per_split) : nt;
+  uint32_t qr[DIMW];
+#pragma unroll
+  for (int k = 0; k < DIMW; ++k) qr[k] = (qi < nq) ? q[qi * DIMW + k] : 0u;
+  float b1d = 3.0e38f, b2d = 3.0e38f; int b1i = -1, b2i = -1;
+  for (int64_t base = t_beg; base < t_end; base += TILE) {
+    const int cnt = (int)((t_end - base) < TILE ? (t_end - base) : TILE);
+    __syncthreads();
+    for (int i = tid; i < cnt * DIMW; i += 256) s_t[i] = t[base * DIMW + i];
+    __syncthreads();
+    for (int r = 0; r < cnt; ++r) {
+      float dist;
+      if (METRIC == 1) {
+        float acc = 0.0f;
+#pragma unroll
+        for (int k = 0; k < DIMW; ++k) {
+          const float diff = __fsub_rn(__uint_as_float(qr[k]), __uint_as_float(s_t[r * DIMW + k]));
+          acc = __fadd_rn(acc, __fmul_rn(diff, diff));
+        }
+        dist = __fsqrt_rn(acc);
+      } else {
+        int pc = 0;
+#pragma unroll
+        for (int k = 0; k < DIMW; ++k) pc += __popc(qr[k] ^ s_t[r * DIMW + k]);
+        dist = (float)pc;
+      }
+      top2_insert(dist, (int)(base + r), b1d, b1i, b2d, b2i);
+    }
+  }
+  if (qi < nq) {
+    Cand* o = part + ((int64_t)split * nq + qi) * 2;
+    o[0].d = b1i >= 0 ? b1d : 0.0f; o[0].i = b1i;
+    o[1].d = b2i >= 0 ? b2d : 0.0f; o[1].i = b2i;
+  }
+}
+
+// merge the per-split candidates of each query: order by (distance, index)
+__global__ __launch_bounds__(256) void k_merge_splits(int64_t nq, int nsplit, const Cand* __restrict__ part,
+                                                      int* __restrict__ idx1, int* __restrict__ idx2,
+                                                      float* __restrict__ d1, float* __restrict__ d2) {
+  const int64_t qi = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (qi >= nq) return;
+  float b1d = 3.0e38f, b2d = 3.0e38f; int b1i = -1, b2i = -1;
+  for (int s = 0; s < nsplit; ++s) {
+    const Cand* c = part + ((int64_t)s * nq + qi) * 2;
+    top2_insert(c[0].d, c[0].i, b1d, b1i, b2d, b2i);
+    top2_insert(c[1].d, c[1].i, b1d, b1i, b2d, b2i);
+  }
+  idx1[qi] = b1i; idx2[qi] = b2i; d1[qi] = b1d; d2[qi] = b2d;
+}
+
+// ------------------------------------------------------------------------------------ ratio test + compaction
+__global__ __launch_bounds__(256) void k_ratio_count(int64_t nq, const float* __restrict__ d1,
+                                                     const float* __restrict__ d2, double ratio,
+                                                     int* __restrict__ blk_cnt) {
+  __shared__ int s_c[4];
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const bool keep = (i < nq) && ((double)d1[i] < ratio * (double)d2[i]);
+  const unsigned long long b = __ballot(keep);
+  if ((threadIdx.x & 63) == 0) s_c[threadIdx.x >> 6] = __popcll(b);
+  __syncthreads();
+  if (threadIdx.x == 0) blk_cnt[blockIdx.x] = s_c[0] + s_c[1] + s_c[2] + s_c[3];
+}
+__global__ void k_ratio_scan(int nblk, const int* __restrict__ blk_cnt, int* __restrict__ blk_off,
+                             int64_t* __restrict__ total) {
+  if (blockIdx.x != 0 || threadIdx.x != 0) return;
+  int64_t run = 0;
+  for (int i = 0; i < nblk; ++i) { blk_off[i] = (int)run; run += blk_cnt[i]; }
+  *total = run;
+}
+__global__ __launch_bounds__(256) void k_ratio_scatter(int64_t nq, const int* __restrict__ idx1,
+                                                       const float* __restrict__ d1, const float* __restrict__ d2,
+                                                       double ratio, const int* __restrict__ blk_off,
+                                                       int* __restrict__ query_idx, int* __restrict__ train_idx,
+                                                       float* __restrict__ dist) {
+  __shared__ int s_c[4];
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const bool keep = (i < nq) && ((double)d1[i] < ratio * (double)d2[i]);
+  const unsigned long long b = __ballot(keep);
+  if (lane == 0) s_c[w] = __popcll(b);
+  __syncthreads();
+  int off = blk_off[blockIdx.x];
+  for (int k = 0; k < w; ++k) off += s_c[k];
+  off += __popcll(b & ((1ull << lane) - 1ull));
+  if (keep) { query_idx[off] = (int)i; train_idx[off] = idx1[i]; dist[off] = d1[i]; }
+}
+
+__global__ __launch_bounds__(256) void k_f32_to_u8(const float* __restrict__ src, int64_t n, uint8_t* __restrict__ dst,
+                                                   int* __restrict__ all_integral) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const float v = src[i];
+  const bool ok = (v >= 0.0f) && (v <= 255.0f) && (v == rintf(v));
+  dst[i] = ok ? (uint8_t)v : 0;
+  if (!ok) *all_integral = 0;
+}
+
+// ------------------------------------------------------------------------------------ host
+static int pick_nsplit(int64_t nq, int64_t nt, int64_t q_per_wg) {
+  // enough workgroups to fill 256 CUs a few times over, but splits of at least 512 train rows
+  int ns = 8;
+  while (ns > 1 && nt / ns < 512) ns >>= 1;
+  (void)nq; (void)q_per_wg;
+  return ns;
+}
+
+extern "C" int sfm_match_workspace_bytes(int metric, int64_t nq, int64_t nt, int dim, int64_t* bytes) {
+  if (!bytes || nq < 0 || nt < 0 || dim <= 0) return SFM_ERR_ARG;
+  (void)metric;
+  int64_t b = 8 * nq * 2 * (int64_t)sizeof(Cand);   // per-split candidates (nsplit <= 8)
+  b = align_up(b, 256) + align_up(nt * 4, 256) + align_up(nq * 4, 256);
+  b += align_up(((nq + 255) / 256) * 8 + 64, 256);
+  *bytes = b + 1024;
+  return SFM_OK;
+}
+
+extern "C" int sfm_match_knn2(sfm_handle h, int metric, const void* q, int64_t nq, const void* t, int64_t nt,
+                              int dim, int32_t* idx1, int32_t* idx2, float* d1, float* d2, void* workspace,
+                              int64_t workspace_bytes) {
+  if (!h) return SFM_ERR_ARG;
+  if (!q || !t || !idx1 || !idx2 || !d1 || !d2 || !workspace) return sfm_fail(h, SFM_ERR_ARG, "sfm_match_knn2", "null pointer");
+  if (nq < 1 || nt < 2) return sfm_fail(h, SFM_ERR_ARG, "sfm_match_knn2", "needs nq >= 1 and nt >= 2");
+  if (nt > 0x7FFFFF00LL || nq > 0x7FFFFF00LL) return sfm_fail(h, SFM_ERR_ARG, "sfm_match_knn2", "too many rows");
+  int64_t need = 0;
+  sfm_match_workspace_bytes(metric, nq, nt, dim, &need);
+  if (workspace_bytes < need) return sfm_fail(h, SFM_ERR_WORKSPACE, "sfm_match_knn2", "workspace too small");
+  char* ws = (char*)workspace;
+  Cand* part = (Cand*)ws;
+  int64_t off = align_up(8 * nq * 2 * (int64_t)sizeof(Cand), 256);
+  int* tn = (int*)(ws + off); off += align_up(nt * 4, 256);
+  int* qn = (int*)(ws + off);
+  int nsplit = 1;
+  if (metric == SFM_METRIC_L2_U8) {
+    if (dim != 32 && dim != 64 && dim != 128)
+      return sfm_fail(h, SFM_ERR_ARG, "sfm_match_knn2", "L2_U8 needs dim 32, 64 or 128");
+    constexpr int QB = 2;
+    nsplit = pick_nsplit(nq, nt, 4 * QB * 32);
+    const int64_t rps = align_up((nt + nsplit - 1) / nsplit, 128);
+    nsplit = (int)((nt + rps - 1) / rps);
+    hipLaunchKernelGGL(k_row_norm_u8, dim3(cdiv(nt, 256)), dim3(256), 0, h->stream, (const uint8_t*)t, nt, dim, 0x80, dim, tn);
+    hipLaunchKernelGGL(k_row_norm_u8, dim3(cdiv(nq, 256)), dim3(256), 0, h->stream, (const uint8_t*)q, nq, dim, 0x7F, 0, qn);
+    const unsigned grid = cdiv(nq, 4 * QB * 32) * nsplit;
+    if (dim == 128)
+      hipLaunchKernelGGL((k_knn2_u8<4, QB>), dim3(grid), dim3(256), 0, h->stream, (const uint8_t*)q, nq, (const uint8_t*)t, nt, tn, qn, nsplit, rps, part);
+    else if (dim == 64)
+      hipLaunchKernelGGL((k_knn2_u8<2, QB>), dim3(grid), dim3(256), 0, h->stream, (const uint8_t*)q, nq, (const uint8_t*)t, nt, tn, qn, nsplit, rps, part);
+    else
+      hipLaunchKernelGGL((k_knn2_u8<1, QB>), dim3(grid), dim3(256), 0, h->stream, (const uint8_t*)q, nq, (const uint8_t*)t, nt, tn, qn, nsplit, rps, part);
+  } else if (metric == SFM_METRIC_L2_F32 || metric == SFM_METRIC_HAMMING) {
+    nsplit = pick_nsplit(nq, nt, 256);
+    const int64_t rps = (nt + nsplit - 1) / nsplit;
+    nsplit = (int)((nt + rps - 1) / rps);
+    const unsigned grid = cdiv(nq, 256) * nsplit;
+    const uint32_t* qq = (const uint32_t*)q; const uint32_t* tt = (const uint32_t*)t;
+    if (metric == SFM_METRIC_L2_F32) {
+      if (dim == 128) hipLaunchKernelGGL((k_knn2_valu<1, 128>), dim3(grid), dim3(256), 0, h->stream, qq, nq, tt, nt, nsplit, rps, part);
+      else if (dim == 64) hipLaunchKernelGGL((k_knn2_valu<1, 64>), dim3(grid), dim3(256), 0, h->stream, qq, nq, tt, nt, nsplit, rps, part);
+      else if (dim == 32) hipLaunchKernelGGL((k_knn2_valu<1, 32>), dim3(grid), dim3(256), 0, h->stream, qq, nq, tt, nt, nsplit, rps, part);
+      else return sfm_fail(h, SFM_ERR_ARG, "sfm_match_knn2", "L2_F32 supports dim 32, 64, 128");
+    } else {
+      if (dim == 32) hipLaunchKernelGGL((k_knn2_valu<2, 8>), dim3(grid), dim3(256), 0, h->stream, qq, nq, tt, nt, nsplit, rps, part);
+      else if (dim == 64) hipLaunchKernelGGL((k_knn2_valu<2, 16>), dim3(grid), dim3(256), 0, h->stream, qq, nq, tt, nt, nsplit, rps, part);
+      else if (dim == 16) hipLaunchKernelGGL((k_knn2_valu<2, 4>), dim3(grid), dim3(256), 0, h->stream, qq, nq, tt, nt, nsplit, rps, part);
+      else return sfm_fail(h, SFM_ERR_ARG, "sfm_match_knn2", "HAMMING supports dim 16, 32, 64 bytes");
+    }
+  } else {
+    return sfm_fail(h, SFM_ERR_ARG, "sfm_match_knn2", "unknown metric");
+  }
+  hipLaunchKernelGGL(k_merge_splits, dim3(cdiv(nq, 256)), dim3(256), 0, h->stream, nq, nsplit, part, idx1, idx2, d1, d2);
+  SFM_LAUNCH_CHECK(h, "sfm_match_knn2");
+  return SFM_OK;
+}
+
+extern "C" int sfm_match_ratio(sfm_handle h, int64_t nq, const int32_t* idx1, const float* d1, const float* d2,
+                               double ratio, int32_t* query_idx, int32_t* train_idx, float* dist,
+                               int64_t* n_matches, void* workspace, int64_t workspace_bytes) {
+  if (!h) return SFM_ERR_ARG;
+  if (!idx1 || !d1 || !d2 || !query_idx || !train_idx || !dist || !n_matches || !workspace || nq < 1)
+    return sfm_fail(h, SFM_ERR_ARG, "sfm_match_ratio", "bad argument");
+  const int nblk = (int)cdiv(nq, 256);
+  if (workspace_bytes < (int64_t)nblk * 8) return sfm_fail(h, SFM_ERR_WORKSPACE, "sfm_match_ratio", "workspace too small");
+  int* blk_cnt = (int*)workspace;
+  int* blk_off = blk_cnt + nblk;
+  hipLaunchKernelGGL(k_ratio_count, dim3(nblk), dim3(256), 0, h->stream, nq, d1, d2, ratio, blk_cnt);
+  hipLaunchKernelGGL(k_ratio_scan, dim3(1), dim3(64), 0, h->stream, nblk, blk_cnt, blk_off, n_matches);
+  hipLaunchKernelGGL(k_ratio_scatter, dim3(nblk), dim3(256), 0, h->stream, nq, idx1, d1, d2, ratio, blk_off,
+                     query_idx, train_idx, dist);
+  SFM_LAUNCH_CHECK(h, "sfm_match_ratio");
+  return SFM_OK;
+}
+
+extern "C" int sfm_match_f32_to_u8(sfm_handle h, const float* src, int64_t n_elems, uint8_t* dst, int32_t* all_integral) {
+  if (!h) return SFM_ERR_ARG;
+  if (!src || !dst || !all_integral || n_elems < 1) return sfm_fail(h, SFM_ERR_ARG, "sfm_match_f32_to_u8", "bad argument");
+  SFM_HIP(h, hipMemsetD32Async((hipDeviceptr_t)all_integral, 1, 1, h->stream));
+  hipLaunchKernelGGL(k_f32_to_u8, dim3(cdiv(n_elems, 256)), dim3(256), 0, h->stream, src, n_elems, dst, all_integral);
+  SFM_LAUNCH_CHECK(h, "sfm_match_f32_to_u8");
+  return SFM_OK;
+}

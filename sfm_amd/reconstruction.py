@@ -1,0 +1,152 @@
+"""Drop-in for the reference's `StructureFromMotion.bundle_adjust` and
+`compute_reconstruction_stats` (/root/reference/utils/sfm_reconstruction.py:401-549, 582-631).
+
+`BundleAdjustMixin` carries the two methods and reads/writes exactly the state the reference's
+methods do (`self.poses`, `self.points3D`, `self.point_tracks`, `self.K`, `self.image_width`,
+`self.image_height`), so it can be mixed into the reference class
+(`class Fast(BundleAdjustMixin, utils.StructureFromMotion)`) or used through the small
+stand-alone `StructureFromMotion` below.  The solve runs on the GPU; there is no CPU fallback.
+"""
+from __future__ import annotations
+
+import logging
+
+import numpy as np
+
+from .rotation import rodrigues, log_so3
+
+BUNDLE_ADJUST_FREQUENCY = 7      # sfm_reconstruction.py:19 (used by the reference's driver loop)
+
+
+def pack_state(poses, points3D, point_tracks, K, cam_dim=10, order="reference"):
+    """The packing step of bundle_adjust (sfm_reconstruction.py:409-451), vectorised where the
+    reference loops.  Camera index = insertion order of `poses`; observations point-major over
+    `track.items()`.  Returns cams [C,d], pts [P,3], cam_idx, pt_idx, uv (the pixel each
+    observation is compared with), ids.
+
+    order="reference" reproduces the reference's residual pairing: projections are stacked
+    camera-by-camera (:480-485) while `points2D` stays point-major (:486), so the q-th observation
+    in stable camera-sorted order is compared with the q-th point-major pixel.
+    order="aligned" compares every observation with its own pixel.
+    """
+    ids = list(poses.keys())
+    id_to_idx = {img_id: i for i, img_id in enumerate(ids)}
+    cams = np.zeros((len(ids), cam_dim))
+    for i, img_id in enumerate(ids):
+        R, t = poses[img_id]
+        cams[i, :3] = log_so3(R)
+        cams[i, 3:6] = np.asarray(t, dtype=np.float64).reshape(3)
+        if cam_dim == 10:
+            cams[i, 6:] = (K[0, 0], K[1, 1], K[0, 2], K[1, 2])
+    pts = np.asarray([np.asarray(p, dtype=np.float64).ravel() for p in points3D], dtype=np.float64).reshape(-1, 3)
+    lens = np.fromiter((len(tr) for tr in point_tracks), dtype=np.int64, count=len(point_tracks))
+    pt_idx = np.repeat(np.arange(len(point_tracks), dtype=np.int64), lens)
+    cam_idx = np.fromiter((id_to_idx[k] for tr in point_tracks for k in tr.keys()), dtype=np.int64,
+                          count=int(lens.sum()))
+    uv = np.asarray([np.asarray(p2, dtype=np.float64).ravel() for tr in point_tracks for p2 in tr.values()],
+                    dtype=np.float64).reshape(-1, 2)
+    if order == "reference":
+        perm = np.argsort(cam_idx, kind="stable")
+        eff = np.empty_like(uv)
+        eff[perm] = uv
+        uv = eff
+    elif order != "aligned":
+        raise ValueError(f"unknown order {order!r}")
+    return cams, pts, cam_idx, pt_idx, uv, ids
+
+
+class BundleAdjustMixin:
+    """bundle_adjust / compute_reconstruction_stats on the GPU, state contract of the reference."""
+
+    ba_order = "reference"     # bug-compatible residual pairing by default; "aligned" opts out
+    ba_cam_dim = 10            # 10 = per-camera intrinsics + regulariser (reference); 6 = fixed K
+    ba_device = 0
+    ba_options = dict(ftol=1e-4, xtol=1e-4, max_nfev=100)     # sfm_reconstruction.py:509-513
+    last_ba_result = None
+
+    def bundle_adjust(self):
+        """Perform bundle adjustment optimization (sfm_reconstruction.py:401).
+        Returns None on success and False on failure, leaving the state untouched on failure."""
+        from .ba import GpuBA
+        from .trf import trf
+        logging.info("Starting bundle adjustment...")
+        if len(self.poses) < 2:
+            logging.warning("Not enough cameras for bundle adjustment")
+            return False
+        try:
+            cams, pts, cam_idx, pt_idx, uv, ids = pack_state(
+                self.poses, self.points3D, self.point_tracks, self.K, self.ba_cam_dim, self.ba_order)
+            if len(uv) == 0:
+                logging.warning("No points for bundle adjustment")
+                return False
+        except Exception as e:      # same contract as sfm_reconstruction.py:449-451
+            logging.error(f"Error preparing bundle adjustment data: {e}")
+            return False
+        K0 = (self.K[0, 0], self.K[1, 1], self.K[0, 2], self.K[1, 2])
+        be = GpuBA(cams, pts, cam_idx, pt_idx, uv, K0, float(self.image_width), float(self.image_height),
+                   device=self.ba_device)
+        x0 = be.x.clone()
+        res = trf(be, **self.ba_options)
+        self.last_ba_result = res
+        if not res.success:
+            logging.warning("Bundle adjustment failed to converge: "
+                            "The maximum number of function evaluations is exceeded.")
+            return False
+        # the reference logs ||objective(x)||_2 (not the Huber cost) before and after (:522-524)
+        cost_initial = self._residual_norm(be, x0)
+        cost_final = self._residual_norm(be, be.x)
+        logging.info(f"Bundle adjustment: cost reduced from {cost_initial:.2f} to {cost_final:.2f}")
+        cams_new, pts_new = be.params()
+        if self.ba_cam_dim == 10:
+            self.K = np.mean([np.array([[c[6], 0, c[8]], [0, c[7], c[9]], [0, 0, 1]]) for c in cams_new], axis=0)
+        for idx, img_id in enumerate(ids):
+            self.poses[img_id] = (rodrigues(cams_new[idx, :3]), cams_new[idx, 3:6].copy())
+        self.points3D = pts_new.tolist()
+        logging.info("Bundle adjustment completed")
+
+    def _residual_norm(self, be, x):
+        """||objective(x)||_2 of the reference's closure: reprojection rows + regulariser rows."""
+        err2 = float((be.reproj_errors(x, shared_k=False) ** 2).sum().item())
+        if self.ba_cam_dim == 10:
+            cams = x[:be.n].reshape(be.C, 10).cpu().numpy()
+            p = be.prob
+            reg = np.stack([(cams[:, 6] - p.fx0) / p.fx0, (cams[:, 7] - cams[:, 6]) / cams[:, 6],
+                            (cams[:, 8] - p.cx0) / p.width, (cams[:, 9] - p.cy0) / p.height]) * p.reg_weight
+            err2 += float((reg ** 2).sum())
+        return float(np.sqrt(err2))
+
+    def compute_reconstruction_stats(self):
+        """Reprojection / track statistics (sfm_reconstruction.py:582-631) with one shared K."""
+        from .ba import GpuBA
+        n_pts, n_cams = len(self.points3D), len(self.poses)
+        lens = [len(t) for t in self.point_tracks]
+        if n_pts == 0 or sum(lens) == 0:
+            return {'mean_reproj_error': 0, 'max_reproj_error': 0, 'mean_track_length': 0,
+                    'max_track_length': 0, 'num_points': n_pts, 'num_cameras': n_cams}
+        cams, pts, cam_idx, pt_idx, uv, _ = pack_state(self.poses, self.points3D, self.point_tracks,
+                                                       self.K, 6, "aligned")
+        K0 = (self.K[0, 0], self.K[1, 1], self.K[0, 2], self.K[1, 2])
+        be = GpuBA(cams, pts, cam_idx, pt_idx, uv, K0, float(self.image_width), float(self.image_height),
+                   device=self.ba_device)
+        err = be.reproj_errors()
+        return {'mean_reproj_error': float(err.mean().item()), 'max_reproj_error': float(err.max().item()),
+                'mean_track_length': float(np.mean(lens)), 'max_track_length': float(np.max(lens)),
+                'num_points': n_pts, 'num_cameras': n_cams}
+
+
+class StructureFromMotion(BundleAdjustMixin):
+    """Minimal stand-alone holder of the reconstruction state (sfm_reconstruction.py:40-59) for
+    users who only need the hot path; the incremental driver loop stays the reference's."""
+
+    def __init__(self, data_dir=None, order="reference", cam_dim=10, device=0):
+        self.data_dir = data_dir
+        self.image_width = 1024
+        self.image_height = 768
+        self.constructed = []
+        self.K = np.array([[1228, 0, 512], [0, 1228, 384], [0, 0, 1]], dtype=np.float64)
+        self.poses = {}
+        self.points3D = []
+        self.point_tracks = []
+        self.ba_order = order
+        self.ba_cam_dim = cam_dim
+        self.ba_device = device

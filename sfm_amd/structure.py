@@ -1,0 +1,105 @@
+"""Host-side index structures of a bundle-adjustment problem (NumPy, built once per problem).
+
+The reference packs observations point-major (/root/reference/utils/sfm_reconstruction.py:430-435);
+everything here is derived from that order: the per-point track ranges, the per-camera
+observation lists and the camera-pair lists that drive the Schur-complement kernel, plus the
+point sharding used when the problem is split over several GPUs.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+import numpy as np
+
+
+@dataclass
+class BAStructure:
+    n_cams: int
+    n_pts: int
+    cam_idx: np.ndarray     # [N] int32
+    pt_idx: np.ndarray      # [N] int32, non-decreasing
+    pt_ptr: np.ndarray      # [P+1] int32
+    cam_ptr: np.ndarray     # [C+1] int32
+    cam_obs: np.ndarray     # [N] int32
+    blk_ptr: np.ndarray     # [C(C+1)/2 + 1] int32
+    pair_k: np.ndarray      # [n_pairs] int32
+    pair_k2: np.ndarray     # [n_pairs] int32
+
+    @property
+    def n_obs(self):
+        return int(self.cam_idx.shape[0])
+
+    @property
+    def n_pairs(self):
+        return int(self.pair_k.shape[0])
+
+
+def block_index(c, c2, n_cams):
+    """Linear index of the upper-triangular camera pair (c <= c2)."""
+    c = np.asarray(c, dtype=np.int64)
+    c2 = np.asarray(c2, dtype=np.int64)
+    return c * n_cams - c * (c - 1) // 2 + (c2 - c)
+
+
+def build_structure(cam_idx, pt_idx, n_cams, n_pts):
+    cam_idx = np.ascontiguousarray(cam_idx, dtype=np.int64)
+    pt_idx = np.ascontiguousarray(pt_idx, dtype=np.int64)
+    N = cam_idx.shape[0]
+    if N == 0:
+        raise ValueError("no observations")
+    if np.any(np.diff(pt_idx) < 0):
+        raise ValueError("observations must be point-major (pt_idx non-decreasing)")
+    if cam_idx.min() < 0 or cam_idx.max() >= n_cams or pt_idx.min() < 0 or pt_idx.max() >= n_pts:
+        raise ValueError("index out of range")
+    pt_ptr = np.zeros(n_pts + 1, dtype=np.int64)
+    np.cumsum(np.bincount(pt_idx, minlength=n_pts), out=pt_ptr[1:])
+    cam_ptr = np.zeros(n_cams + 1, dtype=np.int64)
+    np.cumsum(np.bincount(cam_idx, minlength=n_cams), out=cam_ptr[1:])
+    cam_obs = np.argsort(cam_idx, kind="stable")
+    # every ordered pair (k, k2) of observations on one track with cam(k) < cam(k2), and all
+    # ordered pairs (k == k2 included) with cam(k) == cam(k2)
+    L = (pt_ptr[1:] - pt_ptr[:-1])[pt_idx]                 # track length seen from each observation
+    total = int(L.sum())
+    k = np.repeat(np.arange(N, dtype=np.int64), L)
+    first = np.cumsum(L) - L
+    k2 = np.repeat(pt_ptr[pt_idx], L) + (np.arange(total, dtype=np.int64) - np.repeat(first, L))
+    ck, ck2 = cam_idx[k], cam_idx[k2]
+    keep = ck <= ck2
+    k, k2, ck, ck2 = k[keep], k2[keep], ck[keep], ck2[keep]
+    blk = block_index(ck, ck2, n_cams)
+    order = np.argsort(blk, kind="stable")
+    nblk = n_cams * (n_cams + 1) // 2
+    blk_ptr = np.zeros(nblk + 1, dtype=np.int64)
+    np.cumsum(np.bincount(blk, minlength=nblk), out=blk_ptr[1:])
+    if blk_ptr[-1] >= 2 ** 31 or N >= 2 ** 31:
+        raise ValueError("problem too large for int32 indices")
+    i32 = lambda a: np.ascontiguousarray(a, dtype=np.int32)
+    return BAStructure(int(n_cams), int(n_pts), i32(cam_idx), i32(pt_idx), i32(pt_ptr), i32(cam_ptr),
+                       i32(cam_obs), i32(blk_ptr), i32(k[order]), i32(k2[order]))
+
+
+def partition_points(pt_ptr, world_size):
+    """Contiguous point ranges [lo, hi) per rank, balanced by observation count.
+
+    Points keep all their observations on one rank, so per-point blocks
+    never cross ranks and only the reduced camera system is exchanged.
+    """
+    pt_ptr = np.asarray(pt_ptr, dtype=np.int64)
+    P = pt_ptr.shape[0] - 1
+    N = int(pt_ptr[-1])
+    bounds = [0]
+    for r in range(1, world_size):
+        target = N * r / world_size
+        j = int(np.searchsorted(pt_ptr, target, side="left"))
+        j = min(max(j, bounds[-1]), P)
+        bounds.append(j)
+    bounds.append(P)
+    return [(bounds[r], bounds[r + 1]) for r in range(world_size)]
+
+
+def shard_arrays(cam_idx, pt_idx, uv, pts, lo, hi):
+    """Observations / points of the point range [lo, hi) with point ids rebased to 0."""
+    pt_idx = np.asarray(pt_idx)
+    a = int(np.searchsorted(pt_idx, lo, side="left"))
+    b = int(np.searchsorted(pt_idx, hi, side="left"))
+    return (np.asarray(cam_idx)[a:b].copy(), (pt_idx[a:b] - lo).copy(), np.asarray(uv)[a:b].copy(),
+            np.asarray(pts)[lo:hi].copy())

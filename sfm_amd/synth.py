@@ -13,35 +13,7 @@ K_REF = (1228.0, 1228.0, 512.0, 384.0)
 WIDTH, HEIGHT = 1024.0, 768.0
 
 
-def _rodrigues(rvec):
-    r = np.asarray(rvec, dtype=np.float64).reshape(3)
-    th = float(np.linalg.norm(r))
-    S = np.array([[0, -r[2], r[1]], [r[2], 0, -r[0]], [-r[1], r[0], 0]])
-    if th < 1e-2:
-        z = th * th
-        a = 1.0 - z / 6.0 + z * z / 120.0
-        b = 0.5 - z / 24.0 + z * z / 720.0
-    else:
-        a = np.sin(th) / th
-        b = (1.0 - np.cos(th)) / (th * th)
-    return np.eye(3) + a * S + b * (S @ S)
-
-
-def _log_so3(R):
-    v = np.array([R[2, 1] - R[1, 2], R[0, 2] - R[2, 0], R[1, 0] - R[0, 1]])
-    s = 0.5 * np.linalg.norm(v)
-    c = 0.5 * (np.trace(R) - 1.0)
-    theta = np.arctan2(s, c)
-    if s > 1e-8:
-        return v * (theta / (2.0 * s))
-    if c > 0:
-        return 0.5 * v
-    M = 0.5 * (R + np.eye(3))
-    k = np.sqrt(np.clip(np.diag(M), 0.0, None))
-    i = int(np.argmax(k))
-    sg = np.sign(M[i]); sg[i] = 1.0
-    k = k * sg
-    return k / np.linalg.norm(k) * theta
+from .rotation import rodrigues as _rodrigues, log_so3 as _log_so3
 
 
 @dataclass

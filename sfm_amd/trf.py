@@ -1,0 +1,148 @@
+"""Host state machine of the robust trust-region solve behind `bundle_adjust`.
+
+The reference calls scipy.optimize.least_squares(method='trf', loss='huber', max_nfev=100,
+ftol=1e-4, xtol=1e-4) (/root/reference/utils/sfm_reconstruction.py:506-514).  This module is
+that solver's control flow - trf_no_bounds (scipy _lsq/trf.py:401-560), the More' root finder
+for the Levenberg-Marquardt parameter (scipy _lsq/common.py:57-168), update_tr_radius and
+check_termination (common.py:222-248, 705-717) - driving a *backend* that owns the parameters
+and performs the three data-parallel stages on the GPU:
+
+    backend.linearize()          -> cost, ||g||_2, ||g||_inf          (Jacobian + Huber scaling)
+    backend.solve(alpha, want_q) -> ||p||, p^T (H+alpha I)^-1 p       (damped Schur solve)
+    backend.step(scale)          -> ||J~ s||^2, g^T s, cost(x+s), ||s||, ||x+s||   (s = scale*p)
+    backend.accept()             -> x <- x + s
+
+SciPy gets ||p(alpha)|| and its derivative from one SVD of the Jacobian; here they come from
+solves of (H + alpha I), which is the same function of alpha.  J has a
+7-dof gauge null space, so SciPy's `full_rank` shortcut is never taken and alpha_lower starts at 0.
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass, field
+
+
+@dataclass
+class TRFResult:
+    cost: float
+    nfev: int
+    njev: int
+    status: int
+    optimality: float
+    n_solves: int = 0
+    trace: list = field(default_factory=list)   # (alpha, Delta, step_norm, accepted) per trial
+
+    @property
+    def success(self):
+        return self.status > 0
+
+
+def update_tr_radius(Delta, actual_reduction, predicted_reduction, step_norm, bound_hit):
+    if predicted_reduction > 0:
+        ratio = actual_reduction / predicted_reduction
+    elif predicted_reduction == actual_reduction == 0:
+        ratio = 1
+    else:
+        ratio = 0
+    if ratio < 0.25:
+        Delta = 0.25 * step_norm
+    elif ratio > 0.75 and bound_hit:
+        Delta *= 2.0
+    return Delta, ratio
+
+
+def check_termination(dF, F, dx_norm, x_norm, ratio, ftol, xtol):
+    ftol_satisfied = dF < ftol * F and ratio > 0.25
+    xtol_satisfied = dx_norm < xtol * (xtol + x_norm)
+    if ftol_satisfied and xtol_satisfied:
+        return 4
+    elif ftol_satisfied:
+        return 2
+    elif xtol_satisfied:
+        return 3
+    return None
+
+
+def solve_tr_more(backend, g_norm, Delta, initial_alpha, rtol=0.01, max_iter=10):
+    """More' iteration on alpha; leaves p(alpha_final) in the backend.
+    Returns (||p||, alpha, n_iter, n_solves)."""
+    alpha_upper = g_norm / Delta
+    alpha_lower = 0.0
+    if initial_alpha is None or initial_alpha == 0:
+        alpha = max(0.001 * alpha_upper, (alpha_lower * alpha_upper) ** 0.5)
+    else:
+        alpha = initial_alpha
+    it = -1
+    solves = 0
+    for it in range(max_iter):
+        if alpha < alpha_lower or alpha > alpha_upper:
+            alpha = max(0.001 * alpha_upper, (alpha_lower * alpha_upper) ** 0.5)
+        p_norm, pq = backend.solve(alpha, True)
+        solves += 1
+        phi = p_norm - Delta
+        phi_prime = -pq / p_norm
+        if phi < 0:
+            alpha_upper = alpha
+        ratio = phi / phi_prime
+        alpha_lower = max(alpha_lower, alpha - ratio)
+        alpha -= (phi + Delta) * ratio / Delta
+        if abs(phi) < rtol * Delta:
+            break
+    if not alpha > 0.0:          # the Schur route needs alpha > 0 (SciPy's SVD form does not)
+        alpha = max(0.001 * alpha_upper, 1e-300)
+    p_norm, _ = backend.solve(alpha, False)
+    return p_norm, alpha, it + 1, solves + 1
+
+
+def trf(backend, ftol=1e-4, xtol=1e-4, gtol=1e-8, max_nfev=100, max_outer=None,
+        check_tolerances=True):
+    """Trust-region-reflective loop without bounds.  `max_outer` / `check_tolerances=False`
+    give the fixed-schedule runs used for throughput measurements."""
+    cost, g_norm, g_inf = backend.linearize()
+    nfev, njev = 1, 1
+    x_norm = backend.x_norm()
+    Delta = x_norm if x_norm > 0 else 1.0
+    alpha = 0.0
+    status = None
+    iteration = 0
+    n_solves = 0
+    trace = []
+    while True:
+        if g_inf < gtol and check_tolerances:
+            status = 1
+        if status is not None or nfev == max_nfev:
+            break
+        if max_outer is not None and iteration >= max_outer:
+            break
+        actual_reduction = -1.0
+        cost_new = cost
+        xnew_norm = x_norm
+        while actual_reduction <= 0 and nfev < max_nfev:
+            p_norm, alpha, _, ns = solve_tr_more(backend, g_norm, Delta, alpha)
+            n_solves += ns
+            js2, gts, cost_new, step_norm, xnew_norm = backend.step(Delta / p_norm)
+            predicted_reduction = -(0.5 * js2 + gts)
+            nfev += 1
+            if not math.isfinite(cost_new):
+                Delta = 0.25 * step_norm
+                continue
+            actual_reduction = cost - cost_new
+            Delta_new, ratio = update_tr_radius(Delta, actual_reduction, predicted_reduction,
+                                                step_norm, step_norm > 0.95 * Delta)
+            trace.append((alpha, Delta, step_norm, actual_reduction > 0))
+            if check_tolerances:
+                status = check_termination(actual_reduction, cost, step_norm, x_norm, ratio, ftol, xtol)
+                if status is not None:
+                    break
+            alpha *= Delta / Delta_new
+            Delta = Delta_new
+        if actual_reduction > 0:
+            backend.accept()
+            x_norm = xnew_norm
+            cost = cost_new
+            _, g_norm, g_inf = backend.linearize()
+            njev += 1
+        iteration += 1
+    if status is None:
+        status = 0
+    return TRFResult(cost, nfev, njev, status, g_inf, n_solves, trace)

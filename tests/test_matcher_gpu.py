@@ -1,0 +1,125 @@
+"""GPU parity tests of the matcher (through the C-ABI) against the CPU oracle: bit-exact indices,
+float32-exact distances."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def gpu_knn2(d1, d2, metric="auto"):
+    from sfm_amd import matcher
+    i1, i2, a, b = matcher.knn2(d1, d2, metric)
+    return i1.cpu().numpy(), i2.cpu().numpy(), a.cpu().numpy(), b.cpu().numpy()
+
+
+def assert_knn_equal(got, ref):
+    for g, r, name in zip(got, ref, ("idx1", "idx2", "d1", "d2")):
+        assert np.array_equal(g, r), f"{name}: {np.sum(g != r)} of {len(r)} differ"
+
+
+@pytest.mark.parametrize("nq,nt,dim", [(64, 64, 128), (1, 2, 128), (257, 129, 128), (1000, 1000, 128),
+                                       (777, 3001, 128), (500, 2500, 64), (300, 700, 32)])
+def test_l2_u8_matches_oracle(gpu_ready, nq, nt, dim):
+    from oracle import matcher_oracle as mo
+    from sfm_amd import synth
+    d1, d2 = synth.make_descriptors(nq, nt, seed=nq + nt, dim=dim)
+    u1, u2 = d1.astype(np.uint8), d2.astype(np.uint8)
+    ref = mo.knn2(u1, u2, "l2")
+    assert_knn_equal(gpu_knn2(u1, u2, "l2"), ref)
+    # integer-valued float32 (what SIFT emits) takes the same exact path
+    assert_knn_equal(gpu_knn2(d1, d2, "l2"), ref)
+
+
+def test_l2_u8_uniform_random_bytes(gpu_ready):
+    """Uniform bytes: large d^2 (up to ~2.2e6), every int8 value incl. -128 / 127 on both operands."""
+    from oracle import matcher_oracle as mo
+    rng = np.random.default_rng(7)
+    u1 = rng.integers(0, 256, size=(900, 128), dtype=np.uint8)
+    u2 = rng.integers(0, 256, size=(1500, 128), dtype=np.uint8)
+    u1[0] = 0; u1[1] = 255; u2[0] = 255; u2[1] = 0; u2[2] = 128; u1[2] = 127
+    assert_knn_equal(gpu_knn2(u1, u2, "l2"), mo.knn2(u1, u2, "l2"))
+
+
+def test_l2_ties_and_duplicates(gpu_ready):
+    """Exact duplicates in the train set: the lower train index must come first; d1 == d2 == 0."""
+    from oracle import matcher_oracle as mo
+    from sfm_amd import synth
+    d1, d2 = synth.make_descriptors(300, 600, seed=3)
+    u1, u2 = d1.astype(np.uint8), d2.astype(np.uint8)
+    u2[500] = u2[10]; u2[599] = u2[10]; u2[130] = u2[129]       # duplicates across chunks and splits
+    u1[5] = u2[10]; u1[6] = u2[129]
+    ref = mo.knn2(u1, u2, "l2")
+    got = gpu_knn2(u1, u2, "l2")
+    assert_knn_equal(got, ref)
+    assert (got[0][5], got[1][5], got[2][5], got[3][5]) == (10, 500, 0.0, 0.0)
+    assert (got[0][6], got[1][6]) == (129, 130)
+
+
+def test_l2_f32_general_floats(gpu_ready):
+    from oracle import matcher_oracle as mo
+    from sfm_amd import synth
+    d1, d2 = synth.make_descriptors(400, 900, seed=11, kind="uniform")
+    assert_knn_equal(gpu_knn2(d1, d2, "l2"), mo.knn2(d1, d2, "l2"))
+
+
+@pytest.mark.parametrize("nq,nt", [(64, 64), (1000, 1000), (333, 2049)])
+def test_hamming_matches_oracle(gpu_ready, nq, nt):
+    """The in-tree reference path: ORB 32-byte descriptors, NORM_HAMMING (find_matches.py:144)."""
+    from oracle import matcher_oracle as mo
+    rng = np.random.default_rng(nq)
+    b1 = rng.integers(0, 256, size=(nq, 32), dtype=np.uint8)
+    b2 = rng.integers(0, 256, size=(nt, 32), dtype=np.uint8)
+    b2[: min(nq, nt) // 2] = b1[: min(nq, nt) // 2] ^ rng.integers(0, 2, size=(min(nq, nt) // 2, 32), dtype=np.uint8)
+    assert_knn_equal(gpu_knn2(b1, b2, "auto"), mo.knn2(b1, b2, "hamming"))
+
+
+def test_match_features_contract(gpu_ready):
+    """List of DMatch-like objects, query-ordered, one per query, strict ratio test in double."""
+    from oracle import matcher_oracle as mo
+    from sfm_amd import synth
+    from sfm_amd.matcher import ImageMatcher
+    d1, d2 = synth.make_descriptors(2000, 2300, seed=21)
+    ms = ImageMatcher().match_features(d1, d2)
+    q, t, d = mo.match_features(d1, d2, 0.75, "l2")
+    assert [m.queryIdx for m in ms] == q.tolist()
+    assert [m.trainIdx for m in ms] == t.tolist()
+    assert np.array_equal(np.array([m.distance for m in ms], dtype=np.float32), d)
+    assert all(m.imgIdx == 0 for m in ms)
+    assert np.all(np.diff(q) > 0) and 0 < len(ms) < 2000
+    # distances are sqrtf of an integer, like the reference's shipped match files
+    d2i = np.rint(d.astype(np.float64) ** 2)
+    assert np.array_equal(np.sqrt(d2i.astype(np.float32)), d)
+    assert ImageMatcher().match_features(d1, d2[:1]) == []          # Nt < 2: no matches (documented deviation)
+    assert ImageMatcher().match_features(d1[:0], d2) == []
+
+
+def test_ratio_boundary_is_strict(gpu_ready):
+    """d1 == 0.75 * d2 exactly must be rejected (find_matches.py:152 uses '<')."""
+    from sfm_amd.matcher import match_arrays
+    q = np.zeros((1, 128), np.uint8)
+    t = np.zeros((3, 128), np.uint8)
+    t[0, 0] = 3; t[1, 0] = 4; t[2, 0] = 200                       # d = 3, 4, 200 -> 3 < 0.75*4 is False
+    assert len(match_arrays(q, t, 0.75, "l2")[0]) == 0
+    t[0, 0] = 2
+    qi, ti, d = match_arrays(q, t, 0.75, "l2")
+    assert (qi.tolist(), ti.tolist(), d.tolist()) == ([0], [0], [2.0])
+
+
+def test_full_size_50k_sampled_parity(gpu_ready):
+    """BASELINE config 2 (50k x 50k x 128): every sampled query row is bit-exact against the oracle,
+    and the match list is query-sorted with in-range indices."""
+    import torch
+    from oracle import matcher_oracle as mo
+    from sfm_amd import synth, matcher
+    d1, d2 = synth.make_descriptors(50000, 50000, seed=1002)
+    u1, u2 = d1.astype(np.uint8), d2.astype(np.uint8)
+    i1, i2, a, b = matcher.knn2(torch.from_numpy(u1).cuda(), torch.from_numpy(u2).cuda(), "l2")
+    rows = np.random.default_rng(0).choice(50000, size=384, replace=False)
+    ref = mo.knn2(u1[rows], u2, "l2")
+    got = (i1.cpu().numpy()[rows], i2.cpu().numpy()[rows], a.cpu().numpy()[rows], b.cpu().numpy()[rows])
+    assert_knn_equal(got, ref)
+    q, t, d = matcher.ratio_filter(i1, a, b, 0.75)
+    q, t = q.cpu().numpy(), t.cpu().numpy()
+    assert np.all(np.diff(q) > 0) and t.min() >= 0 and t.max() < 50000
+    keep = a.cpu().numpy().astype(np.float64) < 0.75 * b.cpu().numpy().astype(np.float64)
+    assert np.array_equal(q, np.nonzero(keep)[0])
