@@ -100,8 +100,8 @@ typedef struct {
   int64_t rec_off, rec_stride;      /* per observation: Jc~ [2][cam_dim], Jp~ [2][3], f~ [2] (robust-scaled), doubles */
   int64_t B_off, gc_off;            /* [n_cams][cam_dim][cam_dim], [n_cams][cam_dim]   (this rank's partial sums) */
   int64_t Cp_off, gp_off;           /* [n_pts][6] (xx,xy,xz,yy,yz,zz), [n_pts][3] */
-  int64_t reduce_lin_off, reduce_lin_count;     /* doubles: [gc copy (n_cams*cam_dim) | cost | ||gp||^2 ]  SUM */
-  int64_t gmax_off;                              /* 1 double: max |gp|                                       MAX */
+  int64_t reduce_lin_off, reduce_lin_count;     /* doubles: [gc copy (n) | cost | ||gp||^2 | diag(B) (n)], n = n_cams*cam_dim  SUM */
+  int64_t gmax_off;                              /* 2 doubles: max |gp|, max diag(C_j)                       MAX */
   int64_t reduce_S_off, reduce_S_count;         /* doubles: [S (n x n, n = n_cams*cam_dim) | r (n)]          SUM */
   int64_t reduce_q_off, reduce_q_count;         /* doubles: [rhs2 (n) | ||p_pts||^2 | p_pts^T C_a^-1 p_pts]  SUM */
   int64_t reduce_step_off, reduce_step_count;   /* doubles: [||J~ s||^2 | f~^T J~ s | cost(x+s) | ||s_pts||^2 | ||x_pts+s_pts||^2 ] SUM */
@@ -112,7 +112,7 @@ typedef struct {
 
 enum { SFM_SC_COST = 0, SFM_SC_GNORM2 = 1, SFM_SC_GINF = 2, SFM_SC_PNORM2 = 3, SFM_SC_PQ = 4,
        SFM_SC_JS2 = 5, SFM_SC_GTS = 6, SFM_SC_COST_NEW = 7, SFM_SC_SNORM2 = 8, SFM_SC_XNEW_NORM2 = 9,
-       SFM_SC_CHOL_FAIL = 10, SFM_SC_COUNT = 16 };
+       SFM_SC_CHOL_FAIL = 10, SFM_SC_HDIAG = 11 /* max diag(H) */, SFM_SC_COUNT = 16 };
 
 int sfm_ba_get_layout(int32_t n_cams, int32_t n_pts, int64_t n_obs, int32_t cam_dim, sfm_ba_layout* out_host);
 
@@ -125,7 +125,7 @@ int sfm_ba_reproj_errors(sfm_handle h, const sfm_ba_problem* p, const double* x,
 
 /* Linearise at x: records, B, gc, Cp, gp, cost -> reduce_lin region (+ gmax). */
 int sfm_ba_linearize(sfm_handle h, const sfm_ba_problem* p, const double* x);
-/* After the host has (all-)reduced reduce_lin and gmax: scalars COST, GNORM2, GINF. */
+/* After the host has (all-)reduced reduce_lin and gmax: scalars COST, GNORM2, GINF, HDIAG. */
 int sfm_ba_finish_linearize(sfm_handle h, const sfm_ba_problem* p);
 
 /* Damped solve in three stages around two reductions. */

@@ -21,6 +21,9 @@ reference itself by tests/golden/make_golden.py (parity pinned, see tests/golden
   * the trust-region sub-problem is solved from the normal equations
     H = J~^T J~, g (Cholesky of H + alpha*I) instead of SciPy's dense SVD of J~.
     `full_rank` of scipy:common.py:120-127 is taken as False (7-dof gauge freedom).
+    Where SciPy's iteration would drive alpha to ~0 (Gauss-Newton step inside the trust
+    region; SciPy's own result is round-off dominated there)
+    alpha is floored at ALPHA_FLOOR_REL * max diag(H); never active on the goldens.
 
 Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this.
 """
@@ -30,6 +33,7 @@ from dataclasses import dataclass, field
 import numpy as np
 
 EPS = np.finfo(np.float64).eps
+ALPHA_FLOOR_REL = 1e-13
 
 
 # --------------------------------------------------------------------------- problem
@@ -388,7 +392,7 @@ def dense_solve(H, alpha, rhs):
 
 
 # --------------------------------------------------------------------------- TRF
-def solve_tr_more(solve, g, Delta, initial_alpha, rtol=0.01, max_iter=10):
+def solve_tr_more(solve, g, Delta, initial_alpha, alpha_floor=0.0, rtol=0.01, max_iter=10):
     """scipy common.py:57-168 with the SVD replaced by solves of (H+alpha I).
 
     `solve(alpha, rhs)` returns (H + alpha I)^-1 rhs.  full_rank is False (gauge freedom),
@@ -405,10 +409,15 @@ def solve_tr_more(solve, g, Delta, initial_alpha, rtol=0.01, max_iter=10):
     for it in range(max_iter):
         if alpha < alpha_lower or alpha > alpha_upper:
             alpha = max(0.001 * alpha_upper, (alpha_lower * alpha_upper) ** 0.5)
+        on_floor = alpha <= alpha_floor
+        if on_floor:
+            alpha = alpha_floor
         p = solve(alpha, -g)
         p_norm = np.linalg.norm(p)
-        q = solve(alpha, p)
         phi = p_norm - Delta
+        if on_floor and phi < 0:
+            return p * (Delta / p_norm), alpha, it + 1
+        q = solve(alpha, p)
         phi_prime = -float(np.dot(p, q)) / p_norm
         if phi < 0:
             alpha_upper = alpha
@@ -417,6 +426,7 @@ def solve_tr_more(solve, g, Delta, initial_alpha, rtol=0.01, max_iter=10):
         alpha -= (phi + Delta) * ratio / Delta
         if abs(phi) < rtol * Delta:
             break
+    alpha = max(alpha, alpha_floor, 1e-300)
     p = solve(alpha, -g)
     p *= Delta / np.linalg.norm(p)
     return p, alpha, it + 1
@@ -493,6 +503,8 @@ def trf(prob, x0, ftol=1e-4, xtol=1e-4, gtol=1e-8, max_nfev=100, solver="dense",
         return lambda a, rhs: schur_solve(lin, prob, a, rhs)
 
     solve = make_solver(lin)
+    hdiag = lambda l: max(float(np.max(np.einsum("cii->ci", l.B))), float(np.max(np.einsum("pii->pi", l.Cp))))
+    floor = ALPHA_FLOOR_REL * hdiag(lin)
     while True:
         g_norm = float(np.linalg.norm(g, ord=np.inf))
         if g_norm < gtol:
@@ -505,7 +517,7 @@ def trf(prob, x0, ftol=1e-4, xtol=1e-4, gtol=1e-8, max_nfev=100, solver="dense",
         x_new = x
         cost_new = cost
         while actual_reduction <= 0 and nfev < max_nfev:
-            step, alpha, _ = solve_tr_more(solve, g, Delta, alpha)
+            step, alpha, _ = solve_tr_more(solve, g, Delta, alpha, floor)
             jp = apply_J(lin, prob, step)
             predicted_reduction = -(0.5 * float(np.dot(jp, jp)) + float(np.dot(g, step)))
             x_new = x + step
@@ -533,6 +545,7 @@ def trf(prob, x0, ftol=1e-4, xtol=1e-4, gtol=1e-8, max_nfev=100, solver="dense",
             njev += 1
             g = lin.g
             solve = make_solver(lin)
+            floor = ALPHA_FLOOR_REL * hdiag(lin)
         iteration += 1
     if status is None:
         status = 0

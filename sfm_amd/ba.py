@@ -90,10 +90,10 @@ class GpuBA:
         self.h.call("sfm_ba_linearize", self._pp, C.c_void_p(self.x.data_ptr()))
         if self.comm.world_size > 1:
             self.comm.allreduce_sum(self.view(L.reduce_lin_off, L.reduce_lin_count))
-            self.comm.allreduce_max(self.view(L.gmax_off, 1))
+            self.comm.allreduce_max(self.view(L.gmax_off, 2))
         self.h.call("sfm_ba_finish_linearize", self._pp)
         s = self.scalars()
-        return s[_lib.SC_COST], math.sqrt(s[_lib.SC_GNORM2]), s[_lib.SC_GINF]
+        return s[_lib.SC_COST], math.sqrt(s[_lib.SC_GNORM2]), s[_lib.SC_GINF], s[_lib.SC_HDIAG]
 
     def solve(self, alpha, want_q):
         L = self.lay

@@ -43,8 +43,8 @@ static Lay ba_layout(int64_t C, int64_t P, int64_t N, int64_t D) {
   L.v = take(P * 3);
   L.tmp3 = take(N * 3);
   L.G = take(N * 3 * D);
-  L.red_lin = take(n + 2);
-  L.gmax = take(1);
+  L.red_lin = take(2 * n + 2);
+  L.gmax = take(2);
   L.red_S = take(n * n + n);
   L.red_q = take(n + 2);
   L.red_step = take(8);
@@ -72,7 +72,7 @@ extern "C" int sfm_ba_get_layout(int32_t n_cams, int32_t n_pts, int64_t n_obs, i
   out->rec_off = L.rec * 8; out->rec_stride = (2 * cam_dim + 8) * 8;
   out->B_off = L.B * 8; out->gc_off = L.gc * 8;
   out->Cp_off = L.Cp * 8; out->gp_off = L.gp * 8;
-  out->reduce_lin_off = L.red_lin * 8; out->reduce_lin_count = n + 2;
+  out->reduce_lin_off = L.red_lin * 8; out->reduce_lin_count = 2 * n + 2;
   out->gmax_off = L.gmax * 8;
   out->reduce_S_off = L.red_S * 8; out->reduce_S_count = n * n + n;
   out->reduce_q_off = L.red_q * 8; out->reduce_q_count = n + 2;
@@ -265,7 +265,7 @@ __global__ __launch_bounds__(256) void k_point_blocks(int P, const int* __restri
   constexpr int REC = 2 * D + 8;
   __shared__ double s_red[4];
   const int j = blockIdx.x * 256 + threadIdx.x;
-  double g2 = 0.0, gm = 0.0;
+  double g2 = 0.0, gm = 0.0, cm = 0.0;
   if (j < P) {
     double c0 = 0, c1 = 0, c2 = 0, c3 = 0, c4 = 0, c5 = 0, g0 = 0, g1 = 0, g2v = 0;
     for (int k = pt_ptr[j]; k < pt_ptr[j + 1]; ++k) {
@@ -280,10 +280,12 @@ __global__ __launch_bounds__(256) void k_point_blocks(int P, const int* __restri
     gp[(size_t)j * 3] = g0; gp[(size_t)j * 3 + 1] = g1; gp[(size_t)j * 3 + 2] = g2v;
     g2 = g0 * g0 + g1 * g1 + g2v * g2v;
     gm = fmax(fabs(g0), fmax(fabs(g1), fabs(g2v)));
+    cm = fmax(c0, fmax(c3, c5));
   }
   double t2 = block_sum256(g2, s_red);
   double tm = block_max256(gm, s_red);
-  if (threadIdx.x == 0) { part[blockIdx.x * 2] = t2; part[blockIdx.x * 2 + 1] = tm; }
+  double tc = block_max256(cm, s_red);
+  if (threadIdx.x == 0) { part[blockIdx.x * 4] = t2; part[blockIdx.x * 4 + 1] = tm; part[blockIdx.x * 4 + 2] = tc; }
 }
 
 // per camera: B_c = sum Jc~^T Jc~ (DxD), g_c = sum Jc~^T f~ over the camera's observations.
@@ -374,37 +376,48 @@ __global__ void k_cam_reg(int C, const double* __restrict__ cams, double fx0, do
   for (int r = 0; r < 4; ++r) rr[16 + r] = ft[r];
 }
 
-// Fixed-order sum of block partials -> reduce_lin = [gc copy | cost | ||gp||^2], gmax.
-__global__ __launch_bounds__(256) void k_lin_finalize(int n, const double* __restrict__ gc,
+// Fixed-order sum of block partials -> reduce_lin = [gc copy | cost | ||gp||^2 | diag(B)], gmax = [max|gp|, max diag C].
+__global__ __launch_bounds__(256) void k_lin_finalize(int n, int D, const double* __restrict__ gc,
+                                                      const double* __restrict__ B,
                                                       const double* __restrict__ part_obs, int nblk_obs,
                                                       const double* __restrict__ part_pt, int nblk_pt,
                                                       const double* __restrict__ cost_reg, int n_reg,
                                                       double* __restrict__ red_lin, double* __restrict__ gmax) {
   __shared__ double s_red[4];
   const int tid = threadIdx.x;
-  for (int i = tid; i < n; i += 256) red_lin[i] = gc[i];
-  double c = 0.0, g2 = 0.0, gm = 0.0;
+  for (int i = tid; i < n; i += 256) {
+    red_lin[i] = gc[i];
+    const int cam = i / D, a = i - cam * D;
+    red_lin[n + 2 + i] = B[(size_t)cam * D * D + a * D + a];
+  }
+  double c = 0.0, g2 = 0.0, gm = 0.0, cm = 0.0;
   for (int i = tid; i < nblk_obs; i += 256) c += part_obs[i];
   for (int i = tid; i < n_reg; i += 256) c += cost_reg[i];
-  for (int i = tid; i < nblk_pt; i += 256) { g2 += part_pt[2 * i]; gm = fmax(gm, part_pt[2 * i + 1]); }
+  for (int i = tid; i < nblk_pt; i += 256) { g2 += part_pt[4 * i]; gm = fmax(gm, part_pt[4 * i + 1]); cm = fmax(cm, part_pt[4 * i + 2]); }
   double ct = block_sum256(c, s_red);
   double g2t = block_sum256(g2, s_red);
   double gmt = block_max256(gm, s_red);
-  if (tid == 0) { red_lin[n] = ct; red_lin[n + 1] = g2t; gmax[0] = gmt; }
+  double cmt = block_max256(cm, s_red);
+  if (tid == 0) { red_lin[n] = ct; red_lin[n + 1] = g2t; gmax[0] = gmt; gmax[1] = cmt; }
 }
 
 __global__ __launch_bounds__(256) void k_finish_linearize(int n, const double* __restrict__ red_lin,
                                                           const double* __restrict__ gmax,
                                                           double* __restrict__ sc) {
   __shared__ double s_red[4];
-  double g2 = 0.0, gm = 0.0;
-  for (int i = threadIdx.x; i < n; i += 256) { double v = red_lin[i]; g2 += v * v; gm = fmax(gm, fabs(v)); }
+  double g2 = 0.0, gm = 0.0, hm = 0.0;
+  for (int i = threadIdx.x; i < n; i += 256) {
+    double v = red_lin[i]; g2 += v * v; gm = fmax(gm, fabs(v));
+    hm = fmax(hm, red_lin[n + 2 + i]);
+  }
   double g2t = block_sum256(g2, s_red);
   double gmt = block_max256(gm, s_red);
+  double hmt = block_max256(hm, s_red);
   if (threadIdx.x == 0) {
     sc[SFM_SC_COST] = red_lin[n];
     sc[SFM_SC_GNORM2] = g2t + red_lin[n + 1];
     sc[SFM_SC_GINF] = fmax(gmt, gmax[0]);
+    sc[SFM_SC_HDIAG] = fmax(hmt, gmax[1]);
   }
 }
 
@@ -1088,7 +1101,7 @@ extern "C" int sfm_ba_linearize(sfm_handle h, const sfm_ba_problem* p, const dou
                        p->width, p->height, p->reg_weight, WS(L, B), WS(L, gc), WS(L, cost_reg), WS(L, regrec));
   }
   // cost_reg is [C][4] in the step stage and [C] here: use stride 1 in both by writing column 0 only
-  hipLaunchKernelGGL(k_lin_finalize, dim3(1), dim3(256), 0, h->stream, n, WS(L, gc), WS(L, part_obs),
+  hipLaunchKernelGGL(k_lin_finalize, dim3(1), dim3(256), 0, h->stream, n, D, WS(L, gc), WS(L, B), WS(L, part_obs),
                      (int)L.nblk_obs, WS(L, part_pt), (int)L.nblk_pt, WS(L, cost_reg), nreg, WS(L, red_lin),
                      WS(L, gmax));
   SFM_LAUNCH_CHECK(h, "sfm_ba_linearize");

@@ -7,7 +7,7 @@ for the Levenberg-Marquardt parameter (scipy _lsq/common.py:57-168), update_tr_r
 check_termination (common.py:222-248, 705-717) - driving a *backend* that owns the parameters
 and performs the three data-parallel stages on the GPU:
 
-    backend.linearize()          -> cost, ||g||_2, ||g||_inf          (Jacobian + Huber scaling)
+    backend.linearize()          -> cost, ||g||_2, ||g||_inf, max diag(H)   (Jacobian + Huber scaling)
     backend.solve(alpha, want_q) -> ||p||, p^T (H+alpha I)^-1 p       (damped Schur solve)
     backend.step(scale)          -> ||J~ s||^2, g^T s, cost(x+s), ||s||, ||x+s||   (s = scale*p)
     backend.accept()             -> x <- x + s
@@ -15,11 +15,20 @@ and performs the three data-parallel stages on the GPU:
 SciPy gets ||p(alpha)|| and its derivative from one SVD of the Jacobian; here they come from
 solves of (H + alpha I), which is the same function of alpha.  J has a
 7-dof gauge null space, so SciPy's `full_rank` shortcut is never taken and alpha_lower starts at 0.
+
+One deliberate difference: when the Gauss-Newton step lies inside the trust region SciPy's iteration
+drives alpha towards 0 (x 0.001 per pass) and its SVD step is then dominated by round-off in the gauge
+directions (SURVEY.md section 0 fact 8 - SciPy does not reproduce itself there).  A Cholesky route needs
+H + alpha I numerically positive definite, so alpha is floored at ALPHA_FLOOR_REL * max diag(H) and the
+iteration stops once it sits on the floor with ||p|| < Delta.  The floor is never active in the damped
+regime the reference's own runs exercise (all goldens), where the alpha sequence equals SciPy's.
 """
 from __future__ import annotations
 
 import math
 from dataclasses import dataclass, field
+
+ALPHA_FLOOR_REL = 1e-13
 
 
 @dataclass
@@ -63,7 +72,7 @@ def check_termination(dF, F, dx_norm, x_norm, ratio, ftol, xtol):
     return None
 
 
-def solve_tr_more(backend, g_norm, Delta, initial_alpha, rtol=0.01, max_iter=10):
+def solve_tr_more(backend, g_norm, Delta, initial_alpha, alpha_floor=0.0, rtol=0.01, max_iter=10):
     """More' iteration on alpha; leaves p(alpha_final) in the backend.
     Returns (||p||, alpha, n_iter, n_solves)."""
     alpha_upper = g_norm / Delta
@@ -77,9 +86,14 @@ def solve_tr_more(backend, g_norm, Delta, initial_alpha, rtol=0.01, max_iter=10)
     for it in range(max_iter):
         if alpha < alpha_lower or alpha > alpha_upper:
             alpha = max(0.001 * alpha_upper, (alpha_lower * alpha_upper) ** 0.5)
+        on_floor = alpha <= alpha_floor
+        if on_floor:
+            alpha = alpha_floor
         p_norm, pq = backend.solve(alpha, True)
         solves += 1
         phi = p_norm - Delta
+        if on_floor and phi < 0:          # interior Gauss-Newton step: p(alpha_floor) is the answer
+            return p_norm, alpha, it + 1, solves
         phi_prime = -pq / p_norm
         if phi < 0:
             alpha_upper = alpha
@@ -88,8 +102,7 @@ def solve_tr_more(backend, g_norm, Delta, initial_alpha, rtol=0.01, max_iter=10)
         alpha -= (phi + Delta) * ratio / Delta
         if abs(phi) < rtol * Delta:
             break
-    if not alpha > 0.0:          # the Schur route needs alpha > 0 (SciPy's SVD form does not)
-        alpha = max(0.001 * alpha_upper, 1e-300)
+    alpha = max(alpha, alpha_floor, 1e-300)      # the Schur route needs alpha > 0 (SciPy's SVD form does not)
     p_norm, _ = backend.solve(alpha, False)
     return p_norm, alpha, it + 1, solves + 1
 
@@ -98,7 +111,7 @@ def trf(backend, ftol=1e-4, xtol=1e-4, gtol=1e-8, max_nfev=100, max_outer=None,
         check_tolerances=True):
     """Trust-region-reflective loop without bounds.  `max_outer` / `check_tolerances=False`
     give the fixed-schedule runs used for throughput measurements."""
-    cost, g_norm, g_inf = backend.linearize()
+    cost, g_norm, g_inf, hdiag = backend.linearize()
     nfev, njev = 1, 1
     x_norm = backend.x_norm()
     Delta = x_norm if x_norm > 0 else 1.0
@@ -118,7 +131,7 @@ def trf(backend, ftol=1e-4, xtol=1e-4, gtol=1e-8, max_nfev=100, max_outer=None,
         cost_new = cost
         xnew_norm = x_norm
         while actual_reduction <= 0 and nfev < max_nfev:
-            p_norm, alpha, _, ns = solve_tr_more(backend, g_norm, Delta, alpha)
+            p_norm, alpha, _, ns = solve_tr_more(backend, g_norm, Delta, alpha, ALPHA_FLOOR_REL * hdiag)
             n_solves += ns
             js2, gts, cost_new, step_norm, xnew_norm = backend.step(Delta / p_norm)
             predicted_reduction = -(0.5 * js2 + gts)
@@ -140,7 +153,7 @@ def trf(backend, ftol=1e-4, xtol=1e-4, gtol=1e-8, max_nfev=100, max_outer=None,
             backend.accept()
             x_norm = xnew_norm
             cost = cost_new
-            _, g_norm, g_inf = backend.linearize()
+            _, g_norm, g_inf, hdiag = backend.linearize()
             njev += 1
         iteration += 1
     if status is None:

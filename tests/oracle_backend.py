@@ -40,10 +40,13 @@ class OracleBackend:
     def linearize(self):
         lin = self.lin = bo.linearize(self.x, self.prob)
         n = self.n
-        red = self._sum(np.concatenate([lin.g[:n], [lin.cost, np.sum(lin.g[n:] ** 2)]]))
+        bdiag = np.einsum("cii->ci", lin.B).ravel()
+        red = self._sum(np.concatenate([lin.g[:n], [lin.cost, np.sum(lin.g[n:] ** 2)], bdiag]))
         gmax = self._max(np.max(np.abs(lin.g[n:])) if lin.g.size > n else 0.0)
+        cmax = self._max(np.max(np.einsum("pii->pi", lin.Cp)) if lin.Cp.size else 0.0)
         self.g_c = red[:n]
-        return red[n], math.sqrt(np.sum(red[:n] ** 2) + red[n + 1]), max(np.max(np.abs(red[:n])), gmax)
+        return (red[n], math.sqrt(np.sum(red[:n] ** 2) + red[n + 1]), max(np.max(np.abs(red[:n])), gmax),
+                max(float(np.max(red[n + 2:])), cmax))
 
     def solve(self, alpha, want_q):
         pr, lin, st, n, d = self.prob, self.lin, self.st, self.n, self.prob.d
