@@ -34,6 +34,22 @@ int         sfm_set_stream(sfm_handle h, void* hip_stream);
 int         sfm_synchronize(sfm_handle h);
 const char* sfm_version(void);
 
+/* Per-kernel device timing with HIP events recorded on the handle's stream (what bench.py's
+ * roofline numbers are computed from).  Off by default.  sfm_profile_read synchronises the stream,
+ * returns the accumulated milliseconds and launch count of one slot and resets it. */
+enum { SFM_PROF_LIN_OBS = 0,   /* k_lin_obs: residual + Jacobian + Huber scaling, one launch per linearisation */
+       SFM_PROF_LIN_REST = 1,  /* per-point / per-camera block sums of a linearisation */
+       SFM_PROF_BUILD_G = 2,   /* point factors + G = W L^-T */
+       SFM_PROF_SCHUR = 3,     /* reduced camera system S, r */
+       SFM_PROF_CHOL = 4,      /* dense bordered Cholesky of S */
+       SFM_PROF_TRSV = 5,      /* triangular solves with the factor */
+       SFM_PROF_BACKSUB = 6,   /* point back-substitution and the q pieces */
+       SFM_PROF_STEP = 7,      /* trial step: x + s, predicted reduction sums, cost(x + s) */
+       SFM_PROF_KNN = 8,       /* matcher distance + top-2 kernel */
+       SFM_PROF_COUNT = 9 };
+int sfm_set_profiling(sfm_handle h, int enabled);
+int sfm_profile_read(sfm_handle h, int slot, double* total_ms_host, int64_t* count_host);
+
 /* ------------------------------------------------------------------ matcher
  * Replaces cv2.BFMatcher(norm).knnMatch(desc1, desc2, k=2) + the ratio loop
  * (find_matches.py:144-153).  Distances are float32 as OpenCV's DMatch.distance.

@@ -12,6 +12,7 @@ METRIC_L2_U8, METRIC_L2_F32, METRIC_HAMMING = 0, 1, 2
 (SC_COST, SC_GNORM2, SC_GINF, SC_PNORM2, SC_PQ, SC_JS2, SC_GTS, SC_COST_NEW, SC_SNORM2,
  SC_XNEW_NORM2, SC_CHOL_FAIL, SC_HDIAG) = range(12)
 SC_COUNT = 16
+PROF_SLOTS = ("lin_obs", "lin_rest", "build_G", "schur", "chol", "trsv", "backsub", "step", "knn")
 
 i32, i64, f64, vp = C.c_int32, C.c_int64, C.c_double, C.c_void_p
 
@@ -43,6 +44,8 @@ SIGNATURES = {
     "sfm_set_stream": (C.c_int, [vp, vp]),
     "sfm_synchronize": (C.c_int, [vp]),
     "sfm_version": (C.c_char_p, []),
+    "sfm_set_profiling": (C.c_int, [vp, C.c_int]),
+    "sfm_profile_read": (C.c_int, [vp, C.c_int, C.POINTER(f64), C.POINTER(i64)]),
     "sfm_match_workspace_bytes": (C.c_int, [C.c_int, i64, i64, C.c_int, C.POINTER(i64)]),
     "sfm_match_knn2": (C.c_int, [vp, C.c_int, vp, i64, vp, i64, C.c_int, vp, vp, vp, vp, vp, i64]),
     "sfm_match_ratio": (C.c_int, [vp, i64, vp, vp, vp, f64, vp, vp, vp, vp, vp, i64]),
@@ -112,6 +115,18 @@ class Handle:
 
     def call(self, name, *args):
         self.check(getattr(self.lib, name)(self._h, *args), name)
+
+    def set_profiling(self, on):
+        self.call("sfm_set_profiling", 1 if on else 0)
+
+    def profile(self):
+        """{slot: (total_ms, launches)} since the last read (synchronises); resets the counters."""
+        out = {}
+        for i, name in enumerate(PROF_SLOTS):
+            ms, cnt = f64(), i64()
+            self.call("sfm_profile_read", i, C.byref(ms), C.byref(cnt))
+            out[name] = (ms.value, cnt.value)
+        return out
 
     def __del__(self):
         try:

@@ -1087,8 +1087,11 @@ extern "C" int sfm_ba_linearize(sfm_handle h, const sfm_ba_problem* p, const dou
   DISPATCH_D(D, {
     hipLaunchKernelGGL(k_campre<DD>, dim3(cdiv(C, 64)), dim3(64), 0, h->stream, x, C, p->fx0, p->fy0, p->cx0,
                        p->cy0, WS(L, campre));
+    sfm_prof_begin(h, SFM_PROF_LIN_OBS);
     hipLaunchKernelGGL(k_lin_obs<DD>, dim3((unsigned)L.nblk_obs), dim3(256), 0, h->stream, N, p->cam_idx,
                        p->pt_idx, p->uv, pts, WS(L, campre), WS(L, rec), WS(L, part_obs));
+    sfm_prof_end(h, SFM_PROF_LIN_OBS);
+    sfm_prof_begin(h, SFM_PROF_LIN_REST);
     hipLaunchKernelGGL(k_point_blocks<DD>, dim3((unsigned)L.nblk_pt), dim3(256), 0, h->stream, P, p->pt_ptr,
                        WS(L, rec), WS(L, Cp), WS(L, gp), WS(L, part_pt));
     hipLaunchKernelGGL(k_cam_blocks<DD>, dim3(C), dim3(256), 0, h->stream, p->cam_ptr, p->cam_obs, WS(L, rec),
@@ -1104,6 +1107,7 @@ extern "C" int sfm_ba_linearize(sfm_handle h, const sfm_ba_problem* p, const dou
   hipLaunchKernelGGL(k_lin_finalize, dim3(1), dim3(256), 0, h->stream, n, D, WS(L, gc), WS(L, B), WS(L, part_obs),
                      (int)L.nblk_obs, WS(L, part_pt), (int)L.nblk_pt, WS(L, cost_reg), nreg, WS(L, red_lin),
                      WS(L, gmax));
+  sfm_prof_end(h, SFM_PROF_LIN_REST);
   SFM_LAUNCH_CHECK(h, "sfm_ba_linearize");
   return SFM_OK;
 }
@@ -1123,16 +1127,20 @@ extern "C" int sfm_ba_schur_build(sfm_handle h, const sfm_ba_problem* p, double 
   double* ws = (double*)p->workspace;
   const int C = p->n_cams, P = p->n_pts, D = p->cam_dim, n = C * D;
   const int64_t N = p->n_obs;
+  sfm_prof_begin(h, SFM_PROF_BUILD_G);
   hipLaunchKernelGGL(k_point_factor, dim3(cdiv(P, 256)), dim3(256), 0, h->stream, P, alpha, WS(L, Cp), WS(L, gp),
                      WS(L, Linv), WS(L, e));
   DISPATCH_D(D, {
     const int64_t tot = N * 3 * DD;
     hipLaunchKernelGGL(k_build_G<DD>, dim3(cdiv(tot, 256)), dim3(256), 0, h->stream, tot, p->pt_idx, WS(L, rec),
                        WS(L, Linv), WS(L, G));
+    sfm_prof_end(h, SFM_PROF_BUILD_G);
+    sfm_prof_begin(h, SFM_PROF_SCHUR);
     hipLaunchKernelGGL(k_schur_blocks<DD>, dim3(C, cdiv(C, 4)), dim3(256), 0, h->stream, C, p->blk_ptr,
                        p->pair_k, p->pair_k2, WS(L, G), WS(L, B), WS(L, red_S));
     hipLaunchKernelGGL(k_cam_reduce<DD>, dim3(C), dim3(256), 0, h->stream, p->cam_ptr, p->cam_obs, p->pt_idx,
                        WS(L, G), WS(L, e), WS(L, gc), WS(L, red_S) + (size_t)n * n);
+    sfm_prof_end(h, SFM_PROF_SCHUR);
   });
   SFM_LAUNCH_CHECK(h, "sfm_ba_schur_build");
   return SFM_OK;
@@ -1146,11 +1154,16 @@ extern "C" int sfm_ba_schur_solve(sfm_handle h, const sfm_ba_problem* p, double 
   double* S = WS(L, red_S);
   int* flag = (int*)WS(L, flag);
   SFM_HIP(h, hipMemsetAsync(flag, 0, sizeof(int), h->stream));
+  sfm_prof_begin(h, SFM_PROF_CHOL);
   hipLaunchKernelGGL(k_add_diag, dim3(cdiv(n, 256)), dim3(256), 0, h->stream, S, n, alpha);
   rc = dense_cholesky(h, S, n, n + 1, WS(L, panel), flag); if (rc) return rc;   // row n: r -> L^-1 r
+  sfm_prof_end(h, SFM_PROF_CHOL);
+  sfm_prof_begin(h, SFM_PROF_TRSV);
   // p_c = -L^-T (L^-1 r)
   hipLaunchKernelGGL(k_copy_neg, dim3(cdiv(n, 256)), dim3(256), 0, h->stream, S + (size_t)n * n, WS(L, pc), n, -1.0);
   rc = dense_trsv(h, S, n, WS(L, pc), 1); if (rc) return rc;
+  sfm_prof_end(h, SFM_PROF_TRSV);
+  sfm_prof_begin(h, SFM_PROF_BACKSUB);
   DISPATCH_D(D, hipLaunchKernelGGL(k_obs_Gtp<DD>, dim3(cdiv(N * 3, 256)), dim3(256), 0, h->stream, N * 3,
                                    p->cam_idx, WS(L, G), WS(L, pc), WS(L, tmp3)));
   hipLaunchKernelGGL(k_backsub, dim3((unsigned)L.nblk_pt), dim3(256), 0, h->stream, P, p->pt_ptr, WS(L, tmp3),
@@ -1161,6 +1174,7 @@ extern "C" int sfm_ba_schur_solve(sfm_handle h, const sfm_ba_problem* p, double 
     DISPATCH_D(D, hipLaunchKernelGGL(k_cam_reduce<DD>, dim3(C), dim3(256), 0, h->stream, p->cam_ptr, p->cam_obs,
                                      p->pt_idx, WS(L, G), WS(L, v), (const double*)nullptr, WS(L, red_q)));
   }
+  sfm_prof_end(h, SFM_PROF_BACKSUB);
   SFM_LAUNCH_CHECK(h, "sfm_ba_schur_solve");
   return SFM_OK;
 }
@@ -1171,8 +1185,10 @@ extern "C" int sfm_ba_finish_solve(sfm_handle h, const sfm_ba_problem* p, int wa
   const int n = p->n_cams * p->cam_dim;
   if (want_q) {
     // rhs2 = p_c - W C_a^-1 p_p ;  y = L^-1 rhs2
+    sfm_prof_begin(h, SFM_PROF_TRSV);
     hipLaunchKernelGGL(k_add_vec, dim3(cdiv(n, 256)), dim3(256), 0, h->stream, WS(L, pc), WS(L, red_q), WS(L, y), n);
     rc = dense_trsv(h, WS(L, red_S), n, WS(L, y), 0); if (rc) return rc;
+    sfm_prof_end(h, SFM_PROF_TRSV);
   }
   hipLaunchKernelGGL(k_finish_solve, dim3(1), dim3(256), 0, h->stream, n, WS(L, pc), WS(L, red_q), WS(L, y),
                      want_q, (const int*)WS(L, flag), WS(L, scalars));
@@ -1186,6 +1202,7 @@ extern "C" int sfm_ba_step(sfm_handle h, const sfm_ba_problem* p, const double* 
   const int C = p->n_cams, P = p->n_pts, D = p->cam_dim, n = C * D;
   const int64_t N = p->n_obs, ntot = (int64_t)n + 3 * (int64_t)P;
   double* part_x = WS(L, part_x);
+  sfm_prof_begin(h, SFM_PROF_STEP);
   const unsigned nblk_x = cdiv(ntot, 256), nblk_rows = cdiv(2 * N, 256);
   hipLaunchKernelGGL(k_axpy_step, dim3(nblk_x), dim3(256), 0, h->stream, (int64_t)n, ntot, x, WS(L, pc), WS(L, pp),
                      scale, x_new, part_x);
@@ -1195,6 +1212,7 @@ extern "C" int sfm_ba_step(sfm_handle h, const sfm_ba_problem* p, const double* 
   const int nreg = (D == 10 && p->apply_reg) ? C : 0;
   hipLaunchKernelGGL(k_step_finalize, dim3(1), dim3(256), 0, h->stream, WS(L, part_obs), (int)L.nblk_obs,
                      (int)nblk_rows, part_x, (int)nblk_x, WS(L, cost_reg), nreg, 1, WS(L, red_step));
+  sfm_prof_end(h, SFM_PROF_STEP);
   SFM_LAUNCH_CHECK(h, "sfm_ba_step");
   return SFM_OK;
 }

@@ -6,12 +6,38 @@
 #include <cstdint>
 #include "sfm_amd.h"
 
+#define SFM_PROF_RING 128
+struct sfm_prof_slot {
+  hipEvent_t start[SFM_PROF_RING], stop[SFM_PROF_RING];
+  int pending;             // recorded, not yet folded into total_ms
+  double total_ms;
+  long long count;
+};
+
 struct sfm_ctx {
   int device;
   hipStream_t stream;
   char err[512];
   double* pinned;          // SFM_SC_COUNT doubles of pinned host memory for scalar read-back
+  int profiling;
+  sfm_prof_slot prof[SFM_PROF_COUNT];
 };
+
+// HIP-event bracket around one kernel (or one short kernel sequence) on the handle's stream.
+// No-ops unless sfm_set_profiling(h, 1).  A full ring is folded (which synchronises) before reuse.
+void sfm_prof_fold(sfm_ctx* h, int slot);
+static inline void sfm_prof_begin(sfm_ctx* h, int slot) {
+  if (!h->profiling) return;
+  sfm_prof_slot& s = h->prof[slot];
+  if (s.pending == SFM_PROF_RING) sfm_prof_fold(h, slot);
+  (void)hipEventRecord(s.start[s.pending], h->stream);
+}
+static inline void sfm_prof_end(sfm_ctx* h, int slot) {
+  if (!h->profiling) return;
+  sfm_prof_slot& s = h->prof[slot];
+  (void)hipEventRecord(s.stop[s.pending], h->stream);
+  s.pending++;
+}
 
 static inline int sfm_fail(sfm_ctx* h, int code, const char* what, const char* detail) {
   if (h) snprintf(h->err, sizeof(h->err), "%s: %s", what, detail ? detail : "");

@@ -13,6 +13,8 @@ extern "C" int sfm_create(int device, sfm_handle* out) {
   h->stream = nullptr;
   h->err[0] = 0;
   h->pinned = nullptr;
+  h->profiling = 0;
+  memset(h->prof, 0, sizeof(h->prof));
   if (hipHostMalloc((void**)&h->pinned, SFM_SC_COUNT * sizeof(double), hipHostMallocDefault) != hipSuccess) {
     delete h;
     return SFM_ERR_HIP;
@@ -21,8 +23,49 @@ extern "C" int sfm_create(int device, sfm_handle* out) {
   return SFM_OK;
 }
 
+void sfm_prof_fold(sfm_ctx* h, int slot) {
+  sfm_prof_slot& s = h->prof[slot];
+  for (int i = 0; i < s.pending; ++i) {
+    float ms = 0.f;
+    if (hipEventSynchronize(s.stop[i]) == hipSuccess && hipEventElapsedTime(&ms, s.start[i], s.stop[i]) == hipSuccess) {
+      s.total_ms += ms;
+      s.count++;
+    }
+  }
+  s.pending = 0;
+}
+
+extern "C" int sfm_set_profiling(sfm_handle h, int enabled) {
+  if (!h) return SFM_ERR_ARG;
+  if (enabled && !h->prof[0].start[0]) {
+    for (int k = 0; k < SFM_PROF_COUNT; ++k)
+      for (int i = 0; i < SFM_PROF_RING; ++i) {
+        SFM_HIP(h, hipEventCreate(&h->prof[k].start[i]));
+        SFM_HIP(h, hipEventCreate(&h->prof[k].stop[i]));
+      }
+  }
+  h->profiling = enabled ? 1 : 0;
+  return SFM_OK;
+}
+
+extern "C" int sfm_profile_read(sfm_handle h, int slot, double* total_ms_host, int64_t* count_host) {
+  if (!h || slot < 0 || slot >= SFM_PROF_COUNT || !total_ms_host || !count_host) return SFM_ERR_ARG;
+  sfm_prof_fold(h, slot);
+  *total_ms_host = h->prof[slot].total_ms;
+  *count_host = h->prof[slot].count;
+  h->prof[slot].total_ms = 0.0;
+  h->prof[slot].count = 0;
+  return SFM_OK;
+}
+
 extern "C" void sfm_destroy(sfm_handle h) {
   if (!h) return;
+  if (h->prof[0].start[0])
+    for (int k = 0; k < SFM_PROF_COUNT; ++k)
+      for (int i = 0; i < SFM_PROF_RING; ++i) {
+        (void)hipEventDestroy(h->prof[k].start[i]);
+        (void)hipEventDestroy(h->prof[k].stop[i]);
+      }
   if (h->pinned) (void)hipHostFree(h->pinned);
   delete h;
 }

@@ -231,6 +231,9 @@ __global__ __launch_bounds__(256) void k_knn2_valu(const uint32_t* __restrict__ 
     for (int r = 0; r < cnt; ++r) {
       float dist;
       if (METRIC == 1) {
+        // hipcc defaults to -ffp-contract=fast and would fuse the multiply and the add into one FMA;
+        // the stated order (oracle/matcher_oracle.py: sq_l2) rounds them separately
+#pragma clang fp contract(off)
         float acc = 0.0f;
 #pragma unroll
         for (int k = 0; k < DIMW; ++k) {
@@ -361,12 +364,14 @@ extern "C" int sfm_match_knn2(sfm_handle h, int metric, const void* q, int64_t n
     hipLaunchKernelGGL(k_row_norm_u8, dim3(cdiv(nt, 256)), dim3(256), 0, h->stream, (const uint8_t*)t, nt, dim, 0x80, dim, tn);
     hipLaunchKernelGGL(k_row_norm_u8, dim3(cdiv(nq, 256)), dim3(256), 0, h->stream, (const uint8_t*)q, nq, dim, 0x7F, 0, qn);
     const unsigned grid = cdiv(nq, 4 * QB * 32) * nsplit;
+    sfm_prof_begin(h, SFM_PROF_KNN);
     if (dim == 128)
       hipLaunchKernelGGL((k_knn2_u8<4, QB>), dim3(grid), dim3(256), 0, h->stream, (const uint8_t*)q, nq, (const uint8_t*)t, nt, tn, qn, nsplit, rps, part);
     else if (dim == 64)
       hipLaunchKernelGGL((k_knn2_u8<2, QB>), dim3(grid), dim3(256), 0, h->stream, (const uint8_t*)q, nq, (const uint8_t*)t, nt, tn, qn, nsplit, rps, part);
     else
       hipLaunchKernelGGL((k_knn2_u8<1, QB>), dim3(grid), dim3(256), 0, h->stream, (const uint8_t*)q, nq, (const uint8_t*)t, nt, tn, qn, nsplit, rps, part);
+    sfm_prof_end(h, SFM_PROF_KNN);
   } else if (metric == SFM_METRIC_L2_F32 || metric == SFM_METRIC_HAMMING) {
     nsplit = pick_nsplit(nq, nt, 256);
     const int64_t rps = (nt + nsplit - 1) / nsplit;

@@ -107,55 +107,74 @@ def solve_tr_more(backend, g_norm, Delta, initial_alpha, alpha_floor=0.0, rtol=0
     return p_norm, alpha, it + 1, solves + 1
 
 
+class TRFState:
+    """trf_no_bounds as a steppable object: `outer()` runs one outer iteration (the trials of one
+    linearisation up to the accepted step, then the next linearisation) and returns False once the
+    loop would have ended.  bench.py times K calls of `outer()`."""
+
+    def __init__(self, backend, ftol=1e-4, xtol=1e-4, gtol=1e-8, max_nfev=100, check_tolerances=True):
+        self.be = backend
+        self.ftol, self.xtol, self.gtol, self.max_nfev = ftol, xtol, gtol, max_nfev
+        self.check = check_tolerances
+        self.cost, self.g_norm, self.g_inf, self.hdiag = backend.linearize()
+        self.nfev, self.njev = 1, 1
+        self.x_norm = backend.x_norm()
+        self.Delta = self.x_norm if self.x_norm > 0 else 1.0
+        self.alpha = 0.0
+        self.status = None
+        self.iteration = 0
+        self.n_solves = 0
+        self.trace = []
+
+    def outer(self):
+        be = self.be
+        if self.g_inf < self.gtol and self.check:
+            self.status = 1
+        if self.status is not None or self.nfev == self.max_nfev:
+            return False
+        actual_reduction = -1.0
+        cost_new = self.cost
+        xnew_norm = self.x_norm
+        while actual_reduction <= 0 and self.nfev < self.max_nfev:
+            p_norm, self.alpha, _, ns = solve_tr_more(be, self.g_norm, self.Delta, self.alpha,
+                                                      ALPHA_FLOOR_REL * self.hdiag)
+            self.n_solves += ns
+            js2, gts, cost_new, step_norm, xnew_norm = be.step(self.Delta / p_norm)
+            predicted_reduction = -(0.5 * js2 + gts)
+            self.nfev += 1
+            if not math.isfinite(cost_new):
+                self.Delta = 0.25 * step_norm
+                continue
+            actual_reduction = self.cost - cost_new
+            Delta_new, ratio = update_tr_radius(self.Delta, actual_reduction, predicted_reduction,
+                                                step_norm, step_norm > 0.95 * self.Delta)
+            self.trace.append((self.alpha, self.Delta, step_norm, actual_reduction > 0))
+            if self.check:
+                self.status = check_termination(actual_reduction, self.cost, step_norm, self.x_norm, ratio,
+                                                self.ftol, self.xtol)
+                if self.status is not None:
+                    break
+            self.alpha *= self.Delta / Delta_new
+            self.Delta = Delta_new
+        if actual_reduction > 0:
+            be.accept()
+            self.x_norm = xnew_norm
+            self.cost = cost_new
+            _, self.g_norm, self.g_inf, self.hdiag = be.linearize()
+            self.njev += 1
+        self.iteration += 1
+        return True
+
+    def result(self):
+        return TRFResult(self.cost, self.nfev, self.njev, 0 if self.status is None else self.status,
+                         self.g_inf, self.n_solves, self.trace)
+
+
 def trf(backend, ftol=1e-4, xtol=1e-4, gtol=1e-8, max_nfev=100, max_outer=None,
         check_tolerances=True):
     """Trust-region-reflective loop without bounds.  `max_outer` / `check_tolerances=False`
     give the fixed-schedule runs used for throughput measurements."""
-    cost, g_norm, g_inf, hdiag = backend.linearize()
-    nfev, njev = 1, 1
-    x_norm = backend.x_norm()
-    Delta = x_norm if x_norm > 0 else 1.0
-    alpha = 0.0
-    status = None
-    iteration = 0
-    n_solves = 0
-    trace = []
-    while True:
-        if g_inf < gtol and check_tolerances:
-            status = 1
-        if status is not None or nfev == max_nfev:
-            break
-        if max_outer is not None and iteration >= max_outer:
-            break
-        actual_reduction = -1.0
-        cost_new = cost
-        xnew_norm = x_norm
-        while actual_reduction <= 0 and nfev < max_nfev:
-            p_norm, alpha, _, ns = solve_tr_more(backend, g_norm, Delta, alpha, ALPHA_FLOOR_REL * hdiag)
-            n_solves += ns
-            js2, gts, cost_new, step_norm, xnew_norm = backend.step(Delta / p_norm)
-            predicted_reduction = -(0.5 * js2 + gts)
-            nfev += 1
-            if not math.isfinite(cost_new):
-                Delta = 0.25 * step_norm
-                continue
-            actual_reduction = cost - cost_new
-            Delta_new, ratio = update_tr_radius(Delta, actual_reduction, predicted_reduction,
-                                                step_norm, step_norm > 0.95 * Delta)
-            trace.append((alpha, Delta, step_norm, actual_reduction > 0))
-            if check_tolerances:
-                status = check_termination(actual_reduction, cost, step_norm, x_norm, ratio, ftol, xtol)
-                if status is not None:
-                    break
-            alpha *= Delta / Delta_new
-            Delta = Delta_new
-        if actual_reduction > 0:
-            backend.accept()
-            x_norm = xnew_norm
-            cost = cost_new
-            _, g_norm, g_inf, hdiag = backend.linearize()
-            njev += 1
-        iteration += 1
-    if status is None:
-        status = 0
-    return TRFResult(cost, nfev, njev, status, g_inf, n_solves, trace)
+    st = TRFState(backend, ftol, xtol, gtol, max_nfev, check_tolerances)
+    while (max_outer is None or st.iteration < max_outer) and st.outer():
+        pass
+    return st.result()
