@@ -237,8 +237,9 @@ __global__ __launch_bounds__(256) void k_knn2_valu(const uint32_t* __restrict__ 
         float acc = 0.0f;
 #pragma unroll
         for (int k = 0; k < DIMW; ++k) {
-          const float diff = __fsub_rn(__uint_as_float(qr[k]), __uint_as_float(s_t[r * DIMW + k]));
-          acc = __fadd_rn(acc, __fmul_rn(diff, diff));
+          const float diff = __uint_as_float(qr[k]) - __uint_as_float(s_t[r * DIMW + k]);
+          const float prod = diff * diff;      // plain operators: the pragma is lexical
+          acc = acc + prod;
         }
         dist = __fsqrt_rn(acc);
       } else {
