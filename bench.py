@@ -170,8 +170,9 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         try:
             from oracle import cpu_baseline as cb
-            cpu_baseline = cb.ba_baseline(sc, d, solves_per_iter=n_solves / max(args.steps, 1),
-                                          trials_per_iter=n_trials / max(args.steps, 1))
+            cpu_baseline = cb.ba_baseline(sc, d, warmup=args.warmup, timed=min(3, args.steps))
+            if matcher is not None:
+                cpu_baseline["matcher"] = cb.matcher_baseline(d1.astype(np.uint8), d2.astype(np.uint8))
         except Exception as e:       # the baseline is a reported extra; never fail the GPU measurement on it
             cpu_baseline = {"error": repr(e)}
 

@@ -198,3 +198,39 @@ def test_product_code_never_imports_the_oracle():
             if f.endswith((".py", ".hip", ".h", ".cpp")):
                 src = open(os.path.join(dirpath, f)).read()
                 assert not re.search(r"^\s*(from|import)\s+oracle", src, re.M), f
+
+
+# ------------------------------------------------------------------ C restatement (cpu_baseline) pinned too
+@pytest.mark.parametrize("name", golden_files())
+def test_c_oracle_reproduces_reference_run(name):
+    from oracle import ba_c
+    g, prob, x0 = load_golden_problem(name)
+    cb = ba_c.CBA(prob.n_cams, prob.n_pts, 10, prob.cam_idx, prob.pt_idx, prob.uv, prob.K0)
+    x, r = cb.trf(x0)
+    assert (r["nfev"], r["njev"], r["status"]) == (int(g["nfev"]), int(g["njev"]), int(g["status"]))
+    assert np.max(np.abs(x - g["x"]) / np.maximum(np.abs(g["x"]), 1e-3)) <= 2e-5
+
+
+def test_c_oracle_stages_equal_numpy_oracle():
+    from oracle import ba_c, ba_oracle as bo
+    from sfm_amd import synth
+    sc = synth.make_scene(9, 120, obs_per_point=4, seed=8, cam_sigma=0.01)
+    for d in (10, 6):
+        prob = bo.BAProblem(9, 120, d, sc.cam_idx, sc.pt_idx, sc.uv, np.array(synth.K_REF))
+        x0 = np.concatenate([sc.cams0[:, :d].ravel(), sc.pts0.ravel()])
+        lin = bo.linearize(x0, prob)
+        cb = ba_c.CBA(9, 120, d, sc.cam_idx, sc.pt_idx, sc.uv, synth.K_REF)
+        cost, gn, gi, hd = cb.linearize(x0)
+        assert cost == pytest.approx(lin.cost, rel=1e-12) and gn == pytest.approx(np.linalg.norm(lin.g), rel=1e-11)
+        pn, pq = cb.solve(40.0, True)
+        p_ref = bo.dense_solve(bo.dense_H(lin, prob), 40.0, -lin.g)
+        assert np.linalg.norm(cb.step_vector() - p_ref) <= 1e-7 * np.linalg.norm(p_ref)
+        assert cb.cost(x0) == pytest.approx(lin.cost, rel=1e-12)
+
+
+def test_c_matcher_equals_numpy_oracle():
+    from oracle import ba_c, matcher_oracle as mo
+    from sfm_amd import synth
+    d1, d2 = synth.make_descriptors(300, 500, seed=2)
+    got = ba_c.knn2_u8(d1.astype(np.uint8), d2.astype(np.uint8))
+    assert all(np.array_equal(a, b) for a, b in zip(got, mo.knn2(d1, d2)))
