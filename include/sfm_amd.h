@@ -104,6 +104,14 @@ typedef struct {
   const int32_t* pair_k;     /* [n_pairs] observation of camera c  on a shared track */
   const int32_t* pair_k2;    /* [n_pairs] observation of camera c2 on the same track */
   int64_t n_pairs;
+  const int32_t* item_ptr;   /* [n_cams*(n_cams+1)/2 + 1] work items per block: each <= 256 consecutive pairs of ONE block */
+  const int32_t* item_beg;   /* [n_items] ranges into pair_k / pair_k2 */
+  const int32_t* item_end;   /* [n_items] */
+  int64_t n_items;
+  const int32_t* cch_ptr;    /* [n_cams+1] chunks per camera: each <= 256 consecutive entries of cam_obs of ONE camera */
+  const int32_t* cch_beg;    /* [n_cchunks] ranges into cam_obs */
+  const int32_t* cch_end;    /* [n_cchunks] */
+  int64_t n_cchunks;
   double fx0, fy0, cx0, cy0; /* pre-BA self.K (:492-497); intrinsics of every camera when cam_dim == 6 */
   double width, height, reg_weight;
   void*   workspace;
@@ -130,7 +138,8 @@ enum { SFM_SC_COST = 0, SFM_SC_GNORM2 = 1, SFM_SC_GINF = 2, SFM_SC_PNORM2 = 3, S
        SFM_SC_JS2 = 5, SFM_SC_GTS = 6, SFM_SC_COST_NEW = 7, SFM_SC_SNORM2 = 8, SFM_SC_XNEW_NORM2 = 9,
        SFM_SC_CHOL_FAIL = 10, SFM_SC_HDIAG = 11 /* max diag(H) */, SFM_SC_COUNT = 16 };
 
-int sfm_ba_get_layout(int32_t n_cams, int32_t n_pts, int64_t n_obs, int32_t cam_dim, sfm_ba_layout* out_host);
+int sfm_ba_get_layout(int32_t n_cams, int32_t n_pts, int64_t n_obs, int32_t cam_dim, int64_t n_items,
+                      int64_t n_cchunks, sfm_ba_layout* out_host);
 
 /* cost(x) = 1/2 sum rho(f_i^2) (Huber, per scalar) -> partial into reduce_step[2] (this rank's observations). */
 int sfm_ba_cost(sfm_handle h, const sfm_ba_problem* p, const double* x);

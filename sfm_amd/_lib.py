@@ -23,6 +23,8 @@ class BAProblem(C.Structure):
                 ("cam_idx", vp), ("pt_idx", vp), ("uv", vp), ("pt_ptr", vp), ("cam_ptr", vp),
                 ("cam_obs", vp), ("blk_ptr", vp), ("pair_k", vp), ("pair_k2", vp),
                 ("n_pairs", i64),
+                ("item_ptr", vp), ("item_beg", vp), ("item_end", vp), ("n_items", i64),
+                ("cch_ptr", vp), ("cch_beg", vp), ("cch_end", vp), ("n_cchunks", i64),
                 ("fx0", f64), ("fy0", f64), ("cx0", f64), ("cy0", f64),
                 ("width", f64), ("height", f64), ("reg_weight", f64),
                 ("workspace", vp), ("workspace_bytes", i64)]
@@ -50,7 +52,7 @@ SIGNATURES = {
     "sfm_match_knn2": (C.c_int, [vp, C.c_int, vp, i64, vp, i64, C.c_int, vp, vp, vp, vp, vp, i64]),
     "sfm_match_ratio": (C.c_int, [vp, i64, vp, vp, vp, f64, vp, vp, vp, vp, vp, i64]),
     "sfm_match_f32_to_u8": (C.c_int, [vp, vp, i64, vp, vp]),
-    "sfm_ba_get_layout": (C.c_int, [i32, i32, i64, i32, C.POINTER(BALayout)]),
+    "sfm_ba_get_layout": (C.c_int, [i32, i32, i64, i32, i64, i64, C.POINTER(BALayout)]),
     "sfm_ba_cost": (C.c_int, [vp, C.POINTER(BAProblem), vp]),
     "sfm_ba_reproj_errors": (C.c_int, [vp, C.POINTER(BAProblem), vp, C.c_int, vp]),
     "sfm_ba_linearize": (C.c_int, [vp, C.POINTER(BAProblem), vp]),

@@ -10,7 +10,7 @@
 //   G      [N][3][D]  per observation, per alpha: W_k L_j^-T  (L_j L_j^T = C_j + alpha I)
 //   S | r  [(n+1)][n] reduced camera system with its right-hand side as a bordered row
 // Observations of one point (a track) are contiguous; cameras are reached through cam_obs.
-#include "common.h"
+#include "dense.h"
 
 typedef double v4d __attribute__((ext_vector_type(4)));
 
@@ -21,11 +21,11 @@ typedef double v4d __attribute__((ext_vector_type(4)));
 // ------------------------------------------------------------------------------------ layout
 struct Lay {   // offsets in doubles
   int64_t rec, campre, campre2, B, gc, Cp, gp, Linv, e, v, tmp3, G, red_lin, gmax, red_S, red_q,
-      red_step, pc, pp, y, scalars, part_obs, part_pt, part_x, cost_reg, regrec, panel, flag, total;
+      red_step, pc, pp, y, tvec, scalars, part_obs, part_pt, part_x, cost_reg, regrec, dense, sch_part, cch_part, total;
   int64_t nblk_obs, nblk_pt;
 };
 
-static Lay ba_layout(int64_t C, int64_t P, int64_t N, int64_t D) {
+static Lay ba_layout(int64_t C, int64_t P, int64_t N, int64_t D, int64_t n_items, int64_t n_cchunks) {
   Lay L;
   int64_t o = 0, n = C * D;
   auto take = [&](int64_t cnt) { int64_t r = o; o = align_up(o + cnt, 32); return r; };
@@ -51,22 +51,25 @@ static Lay ba_layout(int64_t C, int64_t P, int64_t N, int64_t D) {
   L.pc = take(n);
   L.pp = take(P * 3);
   L.y = take(n);
+  L.tvec = take(n);
   L.scalars = take(SFM_SC_COUNT);
   L.part_obs = take(L.nblk_obs * 2 * 4 + 4);
   L.part_pt = take(L.nblk_pt * 4);
   L.part_x = take(((n + 3 * P + 255) / 256) * 2 + 2);
   L.cost_reg = take(C * 4);
   L.regrec = take(C * 20);
-  L.panel = take((n + 1) * 32);
-  L.flag = take(4);
+  L.dense = take(dense_ws_doubles((int)n));
+  L.sch_part = take(n_items * D * D);
+  L.cch_part = take(n_cchunks * 16);
   L.total = o;
   return L;
 }
 
-extern "C" int sfm_ba_get_layout(int32_t n_cams, int32_t n_pts, int64_t n_obs, int32_t cam_dim,
-                                 sfm_ba_layout* out) {
-  if (!out || n_cams < 1 || n_pts < 0 || n_obs < 0 || (cam_dim != 6 && cam_dim != 10)) return SFM_ERR_ARG;
-  Lay L = ba_layout(n_cams, n_pts, n_obs, cam_dim);
+extern "C" int sfm_ba_get_layout(int32_t n_cams, int32_t n_pts, int64_t n_obs, int32_t cam_dim, int64_t n_items,
+                                 int64_t n_cchunks, sfm_ba_layout* out) {
+  if (!out || n_cams < 1 || n_pts < 0 || n_obs < 0 || (cam_dim != 6 && cam_dim != 10) || n_items < 0 || n_cchunks < 0)
+    return SFM_ERR_ARG;
+  Lay L = ba_layout(n_cams, n_pts, n_obs, cam_dim, n_items, n_cchunks);
   int64_t n = (int64_t)n_cams * cam_dim;
   out->total_bytes = L.total * 8;
   out->rec_off = L.rec * 8; out->rec_stride = (2 * cam_dim + 8) * 8;
@@ -466,75 +469,94 @@ __global__ __launch_bounds__(256) void k_build_G(int64_t total, const int* __res
   G[i] = r[a] * v0 + r[D + a] * v1;
 }
 
-// Reduced camera system, one wavefront per camera pair (c <= c2):
-//   S[c][c2] = [c == c2] B_c - sum_{(k,k2) on a shared track} G_k G_k2^T        (+ mirrored block)
-// as a K = 4 (3 used) x n_pairs contraction on v_mfma_f64_16x16x4_f64: lane l feeds A[row l&15][k l>>4]
-// = G_k[m = l>>4][row], B likewise from G_k2; C/D: col = l&15, row = (l>>4) + 4*reg.
+// Reduced camera system  S[c][c2] = [c == c2] B_c - sum_{(k,k2) on a shared track} G_k G_k2^T  (c <= c2, mirrored).
+// The pair list of a block is cut into work items of <= 256 pairs (sfm_amd/structure.py); ONE wavefront per
+// item accumulates its 16x16 tile on v_mfma_f64_16x16x4_f64 as a K = 4 (3 used) x n_pairs contraction:
+// lane l feeds A[row l&15][k l>>4] = G_k[m = l>>4][row], B likewise from G_k2; C/D: col = l&15,
+// row = (l>>4) + 4*reg.  Pair ids are loaded 64 at a time (coalesced) and broadcast with v_readlane so the
+// 16 gathers of 8 pairs are in flight together.  k_schur_assemble then sums the items of each block in
+// order (bitwise reproducible), adds B_c on the diagonal and writes the block and its mirror.
 template <int D>
-__global__ __launch_bounds__(256) void k_schur_blocks(int C, const int* __restrict__ blk_ptr,
-                                                      const int* __restrict__ pair_k,
-                                                      const int* __restrict__ pair_k2,
-                                                      const double* __restrict__ G,
-                                                      const double* __restrict__ B, double* __restrict__ S) {
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  const int c = blockIdx.x;
-  const int c2 = c + blockIdx.y * 4 + w;
-  if (c2 >= C) return;
-  const int64_t blk = (int64_t)c * C - (int64_t)c * (c - 1) / 2 + (c2 - c);
-  const int beg = blk_ptr[blk], end = blk_ptr[blk + 1];
+__global__ __launch_bounds__(256) void k_schur_items(int n_items, const int* __restrict__ item_beg,
+                                                     const int* __restrict__ item_end,
+                                                     const int* __restrict__ pair_k, const int* __restrict__ pair_k2,
+                                                     const double* __restrict__ G, double* __restrict__ part) {
+  const int lane = threadIdx.x & 63;
+  const int it = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (it >= n_items) return;
+  const int beg = item_beg[it], end = item_end[it];
   const int row = lane & 15, m = lane >> 4;
   const bool valid = (row < D) && (m < 3);
-  const int off = m * D + row;
+  const int off = valid ? m * D + row : 0;
   v4d acc = {0.0, 0.0, 0.0, 0.0};
-  int p = beg;
-  for (; p + 4 <= end; p += 4) {
-    double a[4], b[4];
+  for (int base = beg; base < end; base += 64) {
+    const int idx = base + lane;
+    const int kk = idx < end ? pair_k[idx] : 0;
+    const int kk2 = idx < end ? pair_k2[idx] : 0;
+    const int cnt = (end - base) < 64 ? (end - base) : 64;
+    int u = 0;
+    for (; u + 8 <= cnt; u += 8) {
+      double a[8], b[8];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const int k = pair_k[p + u], k2 = pair_k2[p + u];
-      a[u] = valid ? G[(size_t)k * (3 * D) + off] : 0.0;
-      b[u] = valid ? G[(size_t)k2 * (3 * D) + off] : 0.0;
+      for (int t = 0; t < 8; ++t) {
+        const int k = __builtin_amdgcn_readlane(kk, u + t), k2 = __builtin_amdgcn_readlane(kk2, u + t);
+        a[t] = valid ? G[(size_t)k * (3 * D) + off] : 0.0;
+        b[t] = valid ? G[(size_t)k2 * (3 * D) + off] : 0.0;
+      }
+#pragma unroll
+      for (int t = 0; t < 8; ++t) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[t], b[t], acc, 0, 0, 0);
     }
-#pragma unroll
-    for (int u = 0; u < 4; ++u) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[u], b[u], acc, 0, 0, 0);
+    for (; u < cnt; ++u) {
+      const int k = __builtin_amdgcn_readlane(kk, u), k2 = __builtin_amdgcn_readlane(kk2, u);
+      const double a = valid ? G[(size_t)k * (3 * D) + off] : 0.0;
+      const double b = valid ? G[(size_t)k2 * (3 * D) + off] : 0.0;
+      acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
+    }
   }
-  for (; p < end; ++p) {
-    const int k = pair_k[p], k2 = pair_k2[p];
-    const double a = valid ? G[(size_t)k * (3 * D) + off] : 0.0;
-    const double b = valid ? G[(size_t)k2 * (3 * D) + off] : 0.0;
-    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
-  }
-  const int n = C * D;
   const int col = lane & 15;
   if (col < D) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int rr = (lane >> 4) + 4 * i;
-      if (rr < D) {
-        double v = -acc[i];
-        if (c == c2) v += B[(size_t)c * D * D + rr * D + col];
-        S[(size_t)(c * D + rr) * n + c2 * D + col] = v;
-        if (c != c2) S[(size_t)(c2 * D + col) * n + c * D + rr] = v;
-      }
+      if (rr < D) part[(size_t)it * (D * D) + rr * D + col] = acc[i];
     }
   }
 }
 
-// out[c][a] = (base ? base[c][a] : 0) - sum_{k in camera c} sum_m G_k[m][a] vec[pt(k)][m]
-// One workgroup per camera: 16 observation slots x 16 lanes (a); slots reduced through LDS in fixed order.
+// grid (C, ceil(C/2)); 128 threads per block pair (c, c2): thread e < D*D owns element (e / D, e % D).
 template <int D>
-__global__ __launch_bounds__(256) void k_cam_reduce(const int* __restrict__ cam_ptr,
-                                                    const int* __restrict__ cam_obs,
-                                                    const int* __restrict__ pt_idx,
-                                                    const double* __restrict__ G,
-                                                    const double* __restrict__ vec,
-                                                    const double* __restrict__ base, double* __restrict__ out) {
+__global__ __launch_bounds__(256) void k_schur_assemble(int C, const int* __restrict__ item_ptr,
+                                                        const double* __restrict__ part,
+                                                        const double* __restrict__ B, double* __restrict__ S) {
+  const int c = blockIdx.x;
+  const int c2 = c + blockIdx.y * 2 + (threadIdx.x >> 7);
+  const int e = threadIdx.x & 127;
+  if (c2 >= C || e >= D * D) return;
+  const int64_t blk = (int64_t)c * C - (int64_t)c * (c - 1) / 2 + (c2 - c);
+  double s = 0.0;
+  for (int it = item_ptr[blk]; it < item_ptr[blk + 1]; ++it) s += part[(size_t)it * (D * D) + e];
+  const int rr = e / D, col = e - rr * D;
+  double v = -s;
+  if (c == c2) v += B[(size_t)c * D * D + e];
+  const int n = C * D;
+  S[(size_t)(c * D + rr) * n + c2 * D + col] = v;
+  if (c != c2) S[(size_t)(c2 * D + col) * n + c * D + rr] = v;
+}
+
+// out[c][a] = (base ? base[c][a] : 0) - sum_{k in camera c} sum_m G_k[m][a] vec[pt(k)][m]
+// Camera lists are cut into chunks of <= 256 observations: one workgroup per chunk (16 observation slots x
+// 16 lanes over a), slots reduced through LDS in fixed order; k_cam_reduce_final sums a camera's chunks in order.
+template <int D>
+__global__ __launch_bounds__(256) void k_cam_reduce_chunks(const int* __restrict__ cch_beg, const int* __restrict__ cch_end,
+                                                           const int* __restrict__ cam_obs, const int* __restrict__ pt_idx,
+                                                           const double* __restrict__ G, const double* __restrict__ vec,
+                                                           double* __restrict__ part) {
   __shared__ double s[16 * 16];
-  const int c = blockIdx.x, tid = threadIdx.x;
+  const int ch = blockIdx.x, tid = threadIdx.x;
   const int slot = tid >> 4, a = tid & 15;
   double acc = 0.0;
   if (a < D) {
-    for (int i = cam_ptr[c] + slot; i < cam_ptr[c + 1]; i += 16) {
+    for (int i = cch_beg[ch] + slot; i < cch_end[ch]; i += 16) {
       const int k = cam_obs[i];
       const double* g = G + (size_t)k * (3 * D) + a;
       const double* v = vec + (size_t)pt_idx[k] * 3;
@@ -543,12 +565,22 @@ __global__ __launch_bounds__(256) void k_cam_reduce(const int* __restrict__ cam_
   }
   s[slot * 16 + a] = acc;
   __syncthreads();
-  if (tid < D) {
+  if (tid < 16) {
     double t = 0.0;
 #pragma unroll
     for (int q = 0; q < 16; ++q) t += s[q * 16 + tid];
-    out[(size_t)c * D + tid] = (base ? base[(size_t)c * D + tid] : 0.0) - t;
+    part[(size_t)ch * 16 + tid] = t;
   }
+}
+template <int D>
+__global__ void k_cam_reduce_final(int C, const int* __restrict__ cch_ptr, const double* __restrict__ part,
+                                   const double* __restrict__ base, double* __restrict__ out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= C * D) return;
+  const int c = i / D, a = i - c * D;
+  double t = 0.0;
+  for (int ch = cch_ptr[c]; ch < cch_ptr[c + 1]; ++ch) t += part[(size_t)ch * 16 + a];
+  out[i] = (base ? base[i] : 0.0) - t;
 }
 
 // tmp3[k][m] = sum_a G_k[m][a] p_c[cam(k)][a]
@@ -608,220 +640,7 @@ __global__ __launch_bounds__(256) void k_sum_partials(const double* __restrict__
   }
 }
 
-// ------------------------------------------------------------------------------------ dense SPD: bordered Cholesky
-// A is [nrows][n] row-major, nrows = n (plain) or n+1 (last row = right-hand side, turned into L^-1 rhs).
-// Right-looking, panel width 32:  k_chol_panel factors the 32x32 diagonal block in ONE wavefront
-// (lane = row, the 32 columns in registers, pivots broadcast by v_readlane) - redundantly in every
-// workgroup - then solves its 256 rows of the panel by forward substitution from LDS;
-// k_chol_update applies the rank-32 update to the trailing lower tiles on v_mfma_f64_16x16x4_f64.
-__device__ __forceinline__ double readlane_d(double v, int l) {
-  int lo = __builtin_amdgcn_readlane(__double2loint(v), l);
-  int hi = __builtin_amdgcn_readlane(__double2hiint(v), l);
-  return __hiloint2double(hi, lo);
-}
-
-// Factor the 32x32 diagonal block in place: one wavefront, lane = row, the 32 columns in registers.
-__global__ __launch_bounds__(64) void k_chol_diag(double* __restrict__ A, int n, int j0, int* __restrict__ fail) {
-  const int i = threadIdx.x;
-  const int nb = (n - j0) < 32 ? (n - j0) : 32;
-  double a[32];
-#pragma unroll
-  for (int q = 0; q < 32; ++q)
-    a[q] = (i < nb && q < nb && q <= i) ? A[(size_t)(j0 + i) * n + j0 + q] : ((q == i) ? 1.0 : 0.0);
-  bool bad = false;
-#pragma unroll
-  for (int j = 0; j < 32; ++j) {
-    double piv = readlane_d(a[j], j);
-    if (!(piv > 0.0)) { bad = true; piv = 1.0; }
-    const double ljj = sqrt(piv);
-    if (i >= j) a[j] = a[j] / ljj;
-#pragma unroll
-    for (int q = j + 1; q < 32; ++q) {
-      const double lqj = readlane_d(a[j], q);
-      if (i >= q) a[q] -= a[j] * lqj;
-    }
-  }
-  if (i < nb) {
-#pragma unroll
-    for (int q = 0; q < 32; ++q)
-      if (q <= i && q < nb) A[(size_t)(j0 + i) * n + j0 + q] = a[q];
-  }
-  if (bad && i == 0) *fail = 1;
-}
-
-// Rows below the diagonal block: x L_jj^T = a by forward substitution, one thread per row, L_jj in LDS.
-__global__ __launch_bounds__(256) void k_chol_panel(double* __restrict__ A, int n, int nrows, int j0,
-                                                    double* __restrict__ panel) {
-  __shared__ double sL[32 * 33];
-  const int tid = threadIdx.x;
-  const int nb = (n - j0) < 32 ? (n - j0) : 32;
-  for (int i = tid; i < 32 * 32; i += 256) {
-    const int r = i >> 5, c = i & 31;
-    sL[r * 33 + c] = (r < nb && c <= r) ? A[(size_t)(j0 + r) * n + j0 + c] : ((r == c) ? 1.0 : 0.0);
-  }
-  __syncthreads();
-  const int j1 = j0 + nb;
-  const int i = j1 + blockIdx.x * 256 + tid;   // global row below the diagonal block
-  if (i >= nrows) return;
-  double x[32];
-  double* arow = A + (size_t)i * n + j0;
-#pragma unroll
-  for (int q = 0; q < 32; ++q) x[q] = (q < nb) ? arow[q] : 0.0;
-#pragma unroll
-  for (int q = 0; q < 32; ++q) {
-    const double xq = x[q] / sL[q * 33 + q];     // rows >= nb of sL are identity rows
-    x[q] = xq;
-#pragma unroll
-    for (int c = q + 1; c < 32; ++c) x[c] -= xq * sL[c * 33 + q];
-  }
-  double* prow = panel + (size_t)(i - j1) * 32;
-  // x[q] is exactly 0 for q >= nb (zero load, identity rows of sL).  The store into A is steered by an
-  // address select, not a branch: 32 predicated branches here made hipcc spill 600+ registers.
-#pragma unroll
-  for (int q = 0; q < 32; ++q) {
-    double* dst = (q < nb) ? (arow + q) : (prow + q);
-    *dst = x[q];
-    prow[q] = x[q];
-  }
-}
-
-__global__ __launch_bounds__(256) void k_chol_update(double* __restrict__ A, int n, int nrows, int j1,
-                                                     const double* __restrict__ panel) {
-  const int ti = blockIdx.y, tj = blockIdx.x;
-  if (tj > ti) return;
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  const int rem_r = nrows - j1, rem_c = n - j1;
-  const int I0 = ti * 64 + w * 16, J0 = tj * 64;
-  if (I0 >= rem_r) return;
-  const int r16 = lane & 15, kq = lane >> 4;
-  v4d acc[4];
-#pragma unroll
-  for (int t = 0; t < 4; ++t) acc[t] = (v4d){0.0, 0.0, 0.0, 0.0};
-  const int ar = I0 + r16;
-  const double* pa = panel + (size_t)ar * 32 + kq;
-  const bool va = ar < rem_r;
-#pragma unroll
-  for (int k0 = 0; k0 < 32; k0 += 4) {
-    const double a = va ? pa[k0] : 0.0;
-#pragma unroll
-    for (int t = 0; t < 4; ++t) {
-      const int br = J0 + t * 16 + r16;
-      const double b = (br < rem_c) ? panel[(size_t)br * 32 + k0 + kq] : 0.0;
-      acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[t], 0, 0, 0);
-    }
-  }
-  const int col16 = lane & 15;
-#pragma unroll
-  for (int t = 0; t < 4; ++t) {
-    const int gc_ = J0 + t * 16 + col16;
-    if (gc_ >= rem_c) continue;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int gr = I0 + (lane >> 4) + 4 * i;
-      if (gr < rem_r && gc_ <= gr) A[(size_t)(j1 + gr) * n + j1 + gc_] -= acc[t][i];
-    }
-  }
-}
-
-// Blocked triangular solves with the factor (block 64, one launch per block step).  In every launch
-// workgroup 0 first finishes the NEXT diagonal block (its own update, then the 64x64 solve in one
-// wavefront) so a step costs one kernel boundary.
-// transpose = 0:  L y = b (top-down);   transpose = 1:  L^T x = b (bottom-up).
-__global__ __launch_bounds__(256) void k_trsv_diag(const double* __restrict__ L, int n, double* __restrict__ b,
-                                                   int blk, int transpose) {
-  __shared__ double sD[64 * 65];
-  const int tid = threadIdx.x;
-  const int r0 = blk * 64;
-  const int nb = (n - r0) < 64 ? (n - r0) : 64;
-  for (int i = tid; i < 64 * 64; i += 256) {
-    const int r = i >> 6, c = i & 63;
-    sD[r * 65 + c] = (r < nb && c <= r) ? L[(size_t)(r0 + r) * n + r0 + c] : 0.0;
-  }
-  __syncthreads();
-  if (tid < 64) {
-    double y = (tid < nb) ? b[r0 + tid] : 0.0;
-    if (!transpose) {
-      for (int j = 0; j < nb; ++j) {
-        const double xj = readlane_d(y, j) / sD[j * 65 + j];
-        if (tid == j) y = xj;
-        else if (tid > j) y -= sD[tid * 65 + j] * xj;
-      }
-    } else {
-      for (int j = nb - 1; j >= 0; --j) {
-        const double xj = readlane_d(y, j) / sD[j * 65 + j];
-        if (tid == j) y = xj;
-        else if (tid < j) y -= sD[j * 65 + tid] * xj;
-      }
-    }
-    if (tid < nb) b[r0 + tid] = y;
-  }
-}
-
-// b[i] -= sum_{j in block} L[i][j] x_j  for rows i after the block (forward), or
-// b[i] -= sum_{j in block} L[j][i] x_j  for rows i before the block (transpose).
-__global__ __launch_bounds__(256) void k_trsv_update(const double* __restrict__ L, int n, double* __restrict__ b,
-                                                     int blk, int transpose) {
-  __shared__ double sx[64];
-  const int tid = threadIdx.x;
-  const int r0 = blk * 64;
-  const int nb = (n - r0) < 64 ? (n - r0) : 64;
-  if (tid < 64) sx[tid] = (tid < nb) ? b[r0 + tid] : 0.0;
-  __syncthreads();
-  if (!transpose) {
-    // one wavefront per row: lanes over the 64 columns of the block (coalesced), wave reduction
-    const int lane = tid & 63, w = tid >> 6;
-    const int i = r0 + nb + blockIdx.x * 4 + w;
-    if (i >= n) return;
-    double t = (lane < nb) ? L[(size_t)i * n + r0 + lane] * sx[lane] : 0.0;
-    t = wave_sum(t);
-    if (lane == 0) b[i] -= t;
-  } else {
-    const int i = blockIdx.x * 256 + tid;
-    if (i >= r0) return;
-    double t = 0.0;
-    for (int j = 0; j < nb; ++j) t += L[(size_t)(r0 + j) * n + i] * sx[j];
-    b[i] -= t;
-  }
-}
-
-static int dense_cholesky(sfm_ctx* h, double* A, int n, int nrows, double* panel, int* flag) {
-  for (int j0 = 0; j0 < n; j0 += 32) {
-    const int nb = (n - j0) < 32 ? (n - j0) : 32;
-    const int j1 = j0 + nb;
-    const int below = nrows - j1;
-    const unsigned g = below > 0 ? cdiv(below, 256) : 1;
-    hipLaunchKernelGGL(k_chol_diag, dim3(1), dim3(64), 0, h->stream, A, n, j0, flag);
-    if (below > 0) {
-      hipLaunchKernelGGL(k_chol_panel, dim3(g), dim3(256), 0, h->stream, A, n, nrows, j0, panel);
-      unsigned T = cdiv(below, 64);
-      hipLaunchKernelGGL(k_chol_update, dim3(T, T), dim3(256), 0, h->stream, A, n, nrows, j1, panel);
-    }
-  }
-  SFM_LAUNCH_CHECK(h, "dense_cholesky");
-  return SFM_OK;
-}
-
-static int dense_trsv(sfm_ctx* h, const double* L, int n, double* b, int transpose) {
-  const int nblk = (n + 63) / 64;
-  if (!transpose) {
-    for (int blk = 0; blk < nblk; ++blk) {
-      hipLaunchKernelGGL(k_trsv_diag, dim3(1), dim3(256), 0, h->stream, L, n, b, blk, 0);
-      const int after = n - (blk * 64 + 64);
-      if (after > 0)
-        hipLaunchKernelGGL(k_trsv_update, dim3(cdiv(after, 4)), dim3(256), 0, h->stream, L, n, b, blk, 0);
-    }
-  } else {
-    for (int blk = nblk - 1; blk >= 0; --blk) {
-      hipLaunchKernelGGL(k_trsv_diag, dim3(1), dim3(256), 0, h->stream, L, n, b, blk, 1);
-      const int before = blk * 64;
-      if (before > 0)
-        hipLaunchKernelGGL(k_trsv_update, dim3(cdiv(before, 256)), dim3(256), 0, h->stream, L, n, b, blk, 1);
-    }
-  }
-  SFM_LAUNCH_CHECK(h, "dense_trsv");
-  return SFM_OK;
-}
-
+// ------------------------------------------------------------------------------------ small vector helpers
 __global__ void k_add_diag(double* __restrict__ A, int n, double alpha) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) A[(size_t)i * n + i] += alpha;
@@ -1009,10 +828,11 @@ static int check_problem(sfm_ctx* h, const sfm_ba_problem* p, Lay* L) {
   if (!p || p->n_cams < 1 || p->n_pts < 1 || p->n_obs < 1 || (p->cam_dim != 6 && p->cam_dim != 10))
     return sfm_fail(h, SFM_ERR_ARG, "sfm_ba", "bad problem sizes / cam_dim");
   if (!p->cam_idx || !p->pt_idx || !p->uv || !p->pt_ptr || !p->cam_ptr || !p->cam_obs || !p->blk_ptr ||
-      (p->n_pairs > 0 && (!p->pair_k || !p->pair_k2)) || !p->workspace)
+      (p->n_pairs > 0 && (!p->pair_k || !p->pair_k2)) || !p->item_ptr || !p->item_beg || !p->item_end ||
+      !p->cch_ptr || !p->cch_beg || !p->cch_end || !p->workspace)
     return sfm_fail(h, SFM_ERR_ARG, "sfm_ba", "null pointer in problem");
   if ((int64_t)p->n_cams * p->cam_dim > 32000) return sfm_fail(h, SFM_ERR_ARG, "sfm_ba", "reduced system too large");
-  *L = ba_layout(p->n_cams, p->n_pts, p->n_obs, p->cam_dim);
+  *L = ba_layout(p->n_cams, p->n_pts, p->n_obs, p->cam_dim, p->n_items, p->n_cchunks);
   if (p->workspace_bytes < L->total * 8) return sfm_fail(h, SFM_ERR_WORKSPACE, "sfm_ba", "workspace too small");
   return SFM_OK;
 }
@@ -1136,10 +956,15 @@ extern "C" int sfm_ba_schur_build(sfm_handle h, const sfm_ba_problem* p, double 
                        WS(L, Linv), WS(L, G));
     sfm_prof_end(h, SFM_PROF_BUILD_G);
     sfm_prof_begin(h, SFM_PROF_SCHUR);
-    hipLaunchKernelGGL(k_schur_blocks<DD>, dim3(C, cdiv(C, 4)), dim3(256), 0, h->stream, C, p->blk_ptr,
-                       p->pair_k, p->pair_k2, WS(L, G), WS(L, B), WS(L, red_S));
-    hipLaunchKernelGGL(k_cam_reduce<DD>, dim3(C), dim3(256), 0, h->stream, p->cam_ptr, p->cam_obs, p->pt_idx,
-                       WS(L, G), WS(L, e), WS(L, gc), WS(L, red_S) + (size_t)n * n);
+    if (p->n_items > 0)
+      hipLaunchKernelGGL(k_schur_items<DD>, dim3(cdiv(p->n_items, 4)), dim3(256), 0, h->stream, (int)p->n_items,
+                         p->item_beg, p->item_end, p->pair_k, p->pair_k2, WS(L, G), WS(L, sch_part));
+    hipLaunchKernelGGL(k_schur_assemble<DD>, dim3(C, cdiv(C, 2)), dim3(256), 0, h->stream, C, p->item_ptr,
+                       WS(L, sch_part), WS(L, B), WS(L, red_S));
+    hipLaunchKernelGGL(k_cam_reduce_chunks<DD>, dim3((unsigned)p->n_cchunks), dim3(256), 0, h->stream, p->cch_beg,
+                       p->cch_end, p->cam_obs, p->pt_idx, WS(L, G), WS(L, e), WS(L, cch_part));
+    hipLaunchKernelGGL(k_cam_reduce_final<DD>, dim3(cdiv(n, 256)), dim3(256), 0, h->stream, C, p->cch_ptr,
+                       WS(L, cch_part), WS(L, gc), WS(L, red_S) + (size_t)n * n);
     sfm_prof_end(h, SFM_PROF_SCHUR);
   });
   SFM_LAUNCH_CHECK(h, "sfm_ba_schur_build");
@@ -1152,16 +977,16 @@ extern "C" int sfm_ba_schur_solve(sfm_handle h, const sfm_ba_problem* p, double 
   const int C = p->n_cams, P = p->n_pts, D = p->cam_dim, n = C * D;
   const int64_t N = p->n_obs;
   double* S = WS(L, red_S);
-  int* flag = (int*)WS(L, flag);
-  SFM_HIP(h, hipMemsetAsync(flag, 0, sizeof(int), h->stream));
+  DenseWs dw; dense_ws_carve(WS(L, dense), n, &dw);
+  SFM_HIP(h, hipMemsetAsync(dw.flag, 0, sizeof(int), h->stream));
   sfm_prof_begin(h, SFM_PROF_CHOL);
   hipLaunchKernelGGL(k_add_diag, dim3(cdiv(n, 256)), dim3(256), 0, h->stream, S, n, alpha);
-  rc = dense_cholesky(h, S, n, n + 1, WS(L, panel), flag); if (rc) return rc;   // row n: r -> L^-1 r
+  rc = dense_cholesky(h, S, n, n + 1, dw); if (rc) return rc;   // row n: r -> L^-1 r
   sfm_prof_end(h, SFM_PROF_CHOL);
   sfm_prof_begin(h, SFM_PROF_TRSV);
   // p_c = -L^-T (L^-1 r)
-  hipLaunchKernelGGL(k_copy_neg, dim3(cdiv(n, 256)), dim3(256), 0, h->stream, S + (size_t)n * n, WS(L, pc), n, -1.0);
-  rc = dense_trsv(h, S, n, WS(L, pc), 1); if (rc) return rc;
+  hipLaunchKernelGGL(k_copy_neg, dim3(cdiv(n, 256)), dim3(256), 0, h->stream, S + (size_t)n * n, WS(L, tvec), n, -1.0);
+  rc = dense_trsv(h, S, n, dw, WS(L, tvec), WS(L, pc), 1); if (rc) return rc;
   sfm_prof_end(h, SFM_PROF_TRSV);
   sfm_prof_begin(h, SFM_PROF_BACKSUB);
   DISPATCH_D(D, hipLaunchKernelGGL(k_obs_Gtp<DD>, dim3(cdiv(N * 3, 256)), dim3(256), 0, h->stream, N * 3,
@@ -1171,8 +996,12 @@ extern "C" int sfm_ba_schur_solve(sfm_handle h, const sfm_ba_problem* p, double 
   hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(256), 0, h->stream, WS(L, part_pt), (int)L.nblk_pt, 2,
                      WS(L, red_q) + n);
   if (want_q) {
-    DISPATCH_D(D, hipLaunchKernelGGL(k_cam_reduce<DD>, dim3(C), dim3(256), 0, h->stream, p->cam_ptr, p->cam_obs,
-                                     p->pt_idx, WS(L, G), WS(L, v), (const double*)nullptr, WS(L, red_q)));
+    DISPATCH_D(D, {
+      hipLaunchKernelGGL(k_cam_reduce_chunks<DD>, dim3((unsigned)p->n_cchunks), dim3(256), 0, h->stream, p->cch_beg,
+                         p->cch_end, p->cam_obs, p->pt_idx, WS(L, G), WS(L, v), WS(L, cch_part));
+      hipLaunchKernelGGL(k_cam_reduce_final<DD>, dim3(cdiv(n, 256)), dim3(256), 0, h->stream, C, p->cch_ptr,
+                         WS(L, cch_part), (const double*)nullptr, WS(L, red_q));
+    });
   }
   sfm_prof_end(h, SFM_PROF_BACKSUB);
   SFM_LAUNCH_CHECK(h, "sfm_ba_schur_solve");
@@ -1183,15 +1012,16 @@ extern "C" int sfm_ba_finish_solve(sfm_handle h, const sfm_ba_problem* p, int wa
   Lay L; int rc = check_problem(h, p, &L); if (rc) return rc;
   double* ws = (double*)p->workspace;
   const int n = p->n_cams * p->cam_dim;
+  DenseWs dw; dense_ws_carve(WS(L, dense), n, &dw);
   if (want_q) {
     // rhs2 = p_c - W C_a^-1 p_p ;  y = L^-1 rhs2
     sfm_prof_begin(h, SFM_PROF_TRSV);
-    hipLaunchKernelGGL(k_add_vec, dim3(cdiv(n, 256)), dim3(256), 0, h->stream, WS(L, pc), WS(L, red_q), WS(L, y), n);
-    rc = dense_trsv(h, WS(L, red_S), n, WS(L, y), 0); if (rc) return rc;
+    hipLaunchKernelGGL(k_add_vec, dim3(cdiv(n, 256)), dim3(256), 0, h->stream, WS(L, pc), WS(L, red_q), WS(L, tvec), n);
+    rc = dense_trsv(h, WS(L, red_S), n, dw, WS(L, tvec), WS(L, y), 0); if (rc) return rc;
     sfm_prof_end(h, SFM_PROF_TRSV);
   }
   hipLaunchKernelGGL(k_finish_solve, dim3(1), dim3(256), 0, h->stream, n, WS(L, pc), WS(L, red_q), WS(L, y),
-                     want_q, (const int*)WS(L, flag), WS(L, scalars));
+                     want_q, (const int*)dw.flag, WS(L, scalars));
   SFM_LAUNCH_CHECK(h, "sfm_ba_finish_solve");
   return SFM_OK;
 }
@@ -1237,19 +1067,3 @@ extern "C" int sfm_ba_read_scalars(sfm_handle h, const sfm_ba_problem* p, double
   return SFM_OK;
 }
 
-// ------------------------------------------------------------------------------------ exported dense helpers
-extern "C" int sfm_dense_cholesky(sfm_handle h, double* a, int32_t n, int32_t* fail_flag) {
-  if (!h || !a || n < 1 || !fail_flag) return SFM_ERR_ARG;
-  double* panel = nullptr;
-  SFM_HIP(h, hipMalloc(&panel, (size_t)(n + 1) * 32 * sizeof(double)));
-  SFM_HIP(h, hipMemsetAsync(fail_flag, 0, sizeof(int), h->stream));
-  int rc = dense_cholesky(h, a, n, n, panel, fail_flag);
-  SFM_HIP(h, hipStreamSynchronize(h->stream));
-  SFM_HIP(h, hipFree(panel));
-  return rc;
-}
-
-extern "C" int sfm_dense_trsv(sfm_handle h, const double* l, int32_t n, double* b, int transpose) {
-  if (!h || !l || !b || n < 1) return SFM_ERR_ARG;
-  return dense_trsv(h, l, n, b, transpose ? 1 : 0);
-}

@@ -23,6 +23,12 @@ class BAStructure:
     blk_ptr: np.ndarray     # [C(C+1)/2 + 1] int32
     pair_k: np.ndarray      # [n_pairs] int32
     pair_k2: np.ndarray     # [n_pairs] int32
+    item_ptr: np.ndarray    # [C(C+1)/2 + 1] int32: work items (<= ITEM_PAIRS pairs of ONE block) per block
+    item_beg: np.ndarray    # [n_items] int32 ranges into pair_k / pair_k2
+    item_end: np.ndarray    # [n_items] int32
+    cch_ptr: np.ndarray     # [C+1] int32: chunks (<= CHUNK_OBS entries of cam_obs of ONE camera) per camera
+    cch_beg: np.ndarray     # [n_cchunks] int32 ranges into cam_obs
+    cch_end: np.ndarray     # [n_cchunks] int32
 
     @property
     def n_obs(self):
@@ -31,6 +37,34 @@ class BAStructure:
     @property
     def n_pairs(self):
         return int(self.pair_k.shape[0])
+
+    @property
+    def n_items(self):
+        return int(self.item_beg.shape[0])
+
+    @property
+    def n_cchunks(self):
+        return int(self.cch_beg.shape[0])
+
+
+ITEM_PAIRS = 256     # pairs per Schur work item (one wavefront)
+CHUNK_OBS = 256      # observations per camera-major reduction chunk (one workgroup)
+
+
+def _split_ranges(ptr, size):
+    """Split every CSR range [ptr[i], ptr[i+1]) into pieces of at most `size`.
+    Returns (piece_ptr [len(ptr)], beg [n_pieces], end [n_pieces])."""
+    ptr = np.asarray(ptr, dtype=np.int64)
+    cnt = np.diff(ptr)
+    npiece = (cnt + size - 1) // size
+    piece_ptr = np.zeros(len(ptr), dtype=np.int64)
+    np.cumsum(npiece, out=piece_ptr[1:])
+    total = int(piece_ptr[-1])
+    owner = np.repeat(np.arange(len(cnt), dtype=np.int64), npiece)
+    within = np.arange(total, dtype=np.int64) - np.repeat(piece_ptr[:-1], npiece)
+    beg = ptr[owner] + within * size
+    end = np.minimum(beg + size, ptr[owner + 1])
+    return piece_ptr, beg, end
 
 
 def block_index(c, c2, n_cams):
@@ -73,8 +107,11 @@ def build_structure(cam_idx, pt_idx, n_cams, n_pts):
     if blk_ptr[-1] >= 2 ** 31 or N >= 2 ** 31:
         raise ValueError("problem too large for int32 indices")
     i32 = lambda a: np.ascontiguousarray(a, dtype=np.int32)
+    item_ptr, item_beg, item_end = _split_ranges(blk_ptr, ITEM_PAIRS)
+    cch_ptr, cch_beg, cch_end = _split_ranges(cam_ptr, CHUNK_OBS)
     return BAStructure(int(n_cams), int(n_pts), i32(cam_idx), i32(pt_idx), i32(pt_ptr), i32(cam_ptr),
-                       i32(cam_obs), i32(blk_ptr), i32(k[order]), i32(k2[order]))
+                       i32(cam_obs), i32(blk_ptr), i32(k[order]), i32(k2[order]),
+                       i32(item_ptr), i32(item_beg), i32(item_end), i32(cch_ptr), i32(cch_beg), i32(cch_end))
 
 
 def partition_points(pt_ptr, world_size):
