@@ -3,15 +3,16 @@
 //
 // The factorisation is latency-bound (n/32 dependent panel steps), so the design minimises the work
 // on that chain and the number of kernel boundaries:
-//   k_chol_panel   : EVERY workgroup factors the 32x32 diagonal block itself in one wavefront
-//                    (lane = row, 32 columns in registers, the finished column broadcast through LDS,
-//                    1/sqrt by v_rsq_f64 + two Newton steps instead of sqrt + divide) and then solves
-//                    its 256 rows of the panel by forward substitution from LDS.  The factored block
-//                    is parked in `Ld` (other workgroups still read the unfactored one from A).
+//   wave_chol32    : 32x32 diagonal block in ONE wavefront (lane = row, columns split over the two
+//                    half-waves, finished column broadcast through LDS, 1/sqrt by v_rsq_f64 + two Newton
+//                    steps instead of sqrt + divide)
+//   wave_inv32     : its inverse, also in one wavefront (lane = column)
+//   k_chol_panel   : rows below the block as a 32-deep MFMA product with L_jj^-1
 //   k_chol_update  : rank-32 update of the trailing lower tiles on v_mfma_f64_16x16x4_f64, panel rows
-//                    staged in LDS (row stride 34 doubles = conflict-free ds_read_b64); copies `Ld`
-//                    into A.                                                 -> 2 launches per step
-//   k_inv64 / k_inv_merge_* : explicit inverses of the 128x128 diagonal blocks of L (both layouts), so
+//                    staged in LDS (row stride 34 doubles = conflict-free ds_read_b64); LOOK-AHEAD: the
+//                    workgroup of tile (0,0) factors the next diagonal block right after updating it, so
+//                    the serial chain has no kernel of its own                -> 2 launches per step
+//   k_inv64 / k_inv_merge : explicit inverses of the 128x128 diagonal blocks of L (both layouts), so
 //   k_trsv_step    : one launch per 128-row block: every workgroup recomputes x_blk = Dinv * rhs_blk
 //                    (coalesced 128-long dot products) and updates its own rows of the right-hand side.
 #include "dense.h"
@@ -54,86 +55,137 @@ void dense_ws_carve(double* base, int n, DenseWs* w) {
 }
 
 // ------------------------------------------------------------------------------------ Cholesky
-__global__ __launch_bounds__(256) void k_chol_panel(double* __restrict__ A, int n, int nrows, int j0,
-                                                    double* __restrict__ panel, double* __restrict__ Ld,
-                                                    int* __restrict__ fail) {
-  __shared__ double sL[32 * 33];
-  __shared__ double scol[2][32];
-  __shared__ double srd[32];
-  const int tid = threadIdx.x;
-  const int nb = (n - j0) < 32 ? (n - j0) : 32;
-  if (tid < 64) {
-    const int i = tid & 31;            // both half-waves run the same rows; only lanes < 32 publish
-    double a[32];
+// In-wave factorisation of a 32x32 SPD block.  Lane l = (row i = l & 31, half h = l >> 5) holds the 16
+// entries M[i][2t + h] of its row in a[t]: the two half-waves split the columns, so a rank-1 update costs
+// <= 16 FMAs per lane.  The finished column is broadcast through LDS (same wavefront: LDS is in order).
+// Writes L (lower, zeros above) to sL[32][33] and the reciprocal diagonal to srd[32]; returns false on a
+// non-positive pivot.  scol: 128 doubles of LDS (2 x 32 column buffers + 64 dump slots: the half-wave
+// that does not own the column stores into the dump slots - an INDEX select; a pointer select or a
+// predicated store here made hipcc use 256 + 92 registers).
+__device__ __forceinline__ bool wave_chol32(double (&a)[16], int lane, double* __restrict__ sL,
+                                            double* __restrict__ srd, double* __restrict__ scol) {
+  const int i = lane & 31, h = lane >> 5;
+  bool bad = false;
 #pragma unroll
-    for (int q = 0; q < 32; ++q)
-      a[q] = (i < nb && q < nb && q <= i) ? A[(size_t)(j0 + i) * n + j0 + q] : ((q == i) ? 1.0 : 0.0);
-    bool bad = false;
-#pragma unroll
-    for (int j = 0; j < 32; ++j) {
-      double piv = readlane_d(a[j], j);
-      if (!(piv > 0.0)) { bad = true; piv = 1.0; }
-      const double rinv = rsqrt_nr(piv);
-      a[j] *= rinv;                                    // lane j: piv * rinv = sqrt(piv); rows above j: unused
-      srd[j] = rinv;                 // every lane stores the same value (uniform) -
-      scol[j & 1][i] = a[j];         // and lanes i, i + 32 hold identical rows: no predication needed
-      // same wavefront, LDS is in order: the reads below see the column just written
-#pragma unroll
-      for (int q = j + 1; q < 32; ++q) a[q] -= a[j] * scol[j & 1][q];
+  for (int j = 0; j < 32; ++j) {
+    const int hj = j & 1, tj = j >> 1;
+    double piv = readlane_d(a[tj], j + 32 * hj);
+    if (!(piv > 0.0)) { bad = true; piv = 1.0; }
+    const double rinv = rsqrt_nr(piv);
+    const double colv = a[tj] * rinv;
+    a[tj] = (h == hj) ? colv : a[tj];
+    double* cb = scol + (j & 1) * 32;
+    scol[(h == hj) ? ((j & 1) * 32 + i) : (64 + lane)] = colv;
+    srd[j] = rinv;                                             // uniform value, every lane stores it
+    const double li = cb[i];                                   // L[i][j] for both halves
+    if (hj == 0) {                                             // column 2 tj + 1 lives in a[tj] of half 1
+      const double upd = li * cb[2 * tj + 1];
+      a[tj] = (h == 1) ? a[tj] - upd : a[tj];
     }
 #pragma unroll
-    for (int q = 0; q < 32; ++q) sL[i * 33 + q] = (q <= i) ? a[q] : 0.0;
-    if (blockIdx.x == 0) {
-#pragma unroll
-      for (int q = 0; q < 32; ++q) Ld[i * 32 + q] = (q <= i) ? a[q] : 0.0;
-    }
-    if (bad && blockIdx.x == 0 && tid == 0) *fail = 1;
+    for (int t = tj + 1; t < 16; ++t) a[t] -= li * cb[2 * t + h];
   }
+#pragma unroll
+  for (int t = 0; t < 16; ++t) {
+    const int q = 2 * t + h;
+    sL[i * 33 + q] = (q <= i) ? a[t] : 0.0;
+  }
+  return !bad;
+}
+
+// Inverse of the 32x32 lower-triangular factor just left in sL (reciprocal diagonal in srd): lane t (both
+// half-waves alike) forward-substitutes column t; L is read from LDS by broadcast.  Result to sLi[32][33].
+__device__ __forceinline__ void wave_inv32(const double* __restrict__ sL, const double* __restrict__ srd, int lane,
+                                           double* __restrict__ sLi) {
+  const int t = lane & 31;
+  double x[32];
+#pragma unroll
+  for (int r = 0; r < 32; ++r) {
+    double s = (r == t) ? 1.0 : 0.0;
+#pragma unroll
+    for (int c = 0; c < r; ++c) s -= sL[r * 33 + c] * x[c];
+    x[r] = (r >= t) ? s * srd[r] : 0.0;
+    sLi[r * 33 + t] = x[r];
+  }
+}
+
+// Factor the first diagonal block (rows/cols j0 .. j0+31) in place; L_jj and 1/diag also go to Ld / rd
+// for the panel kernel.  One wavefront.
+__global__ __launch_bounds__(64) void k_chol_diag(double* __restrict__ A, int n, int j0, double* __restrict__ Ld,
+                                                  double* __restrict__ rd, int* __restrict__ fail) {
+  __shared__ double sL[32 * 33], srd[32], scol[128], sLi[32 * 33];
+  const int lane = threadIdx.x, i = lane & 31, h = lane >> 5;
+  const int nb = (n - j0) < 32 ? (n - j0) : 32;
+  double a[16];
+#pragma unroll
+  for (int t = 0; t < 16; ++t) {
+    const int q = 2 * t + h;
+    a[t] = (i < nb && q < nb && q <= i) ? A[(size_t)(j0 + i) * n + j0 + q] : ((q == i) ? 1.0 : 0.0);
+  }
+  const bool ok = wave_chol32(a, lane, sL, srd, scol);
+  if (!ok && lane == 0) *fail = 1;
+  for (int e = lane; e < 32 * 32; e += 64) {
+    const int r = e >> 5, c = e & 31;
+    const double v = sL[r * 33 + c];
+    if (r < nb && c <= r) A[(size_t)(j0 + r) * n + j0 + c] = v;
+  }
+  wave_inv32(sL, srd, lane, sLi);
+  for (int e = lane; e < 32 * 32; e += 64) Ld[e] = sLi[(e >> 5) * 33 + (e & 31)];     // Ld carries L_jj^-1
+  if (lane < 32) rd[lane] = srd[lane];
+}
+
+// Rows below the diagonal block:  X = A_panel L_jj^-T  as a 32-deep product with the explicit inverse
+// Li = L_jj^-1 (from the look-ahead workgroup):  X[r][c] = sum_{k<=c} A[r][k] Li[c][k]  on
+// v_mfma_f64_16x16x4_f64, wave w = 16 rows, two 16-column tiles.  64 rows per workgroup.
+__global__ __launch_bounds__(256) void k_chol_panel(double* __restrict__ A, int n, int nrows, int j0,
+                                                    double* __restrict__ panel, const double* __restrict__ Li) {
+  constexpr int LDI = 34;
+  __shared__ double sLi[32 * LDI];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int nb = (n - j0) < 32 ? (n - j0) : 32;
+  for (int e = tid; e < 32 * 32; e += 256) sLi[(e >> 5) * LDI + (e & 31)] = Li[e];
   __syncthreads();
   const int j1 = j0 + nb;
-  const int i = j1 + blockIdx.x * 256 + tid;   // global row below the diagonal block
-  if (i >= nrows) return;
-  double x[32];
-  double* arow = A + (size_t)i * n + j0;
+  const int r16 = lane & 15, kq = lane >> 4;
+  const int rbase = j1 + blockIdx.x * 64 + w * 16;     // first global row of this wave
+  if (rbase >= nrows) return;
+  const int arow = rbase + r16;
+  const bool aok = arow < nrows;
+  const double* ap = A + (size_t)arow * n + j0;
+  v4d acc[2] = {(v4d){0.0, 0.0, 0.0, 0.0}, (v4d){0.0, 0.0, 0.0, 0.0}};
 #pragma unroll
-  for (int q = 0; q < 32; ++q) x[q] = (q < nb) ? arow[q] : 0.0;
+  for (int k0 = 0; k0 < 32; k0 += 4) {
+    const double a = (aok && (k0 + kq) < nb) ? ap[k0 + kq] : 0.0;
 #pragma unroll
-  for (int q = 0; q < 32; ++q) {
-    const double xq = x[q] * srd[q];             // rows >= nb of the block are identity rows (rd = 1)
-    x[q] = xq;
-#pragma unroll
-    for (int c = q + 1; c < 32; ++c) x[c] -= xq * sL[c * 33 + q];
-  }
-  double* prow = panel + (size_t)(i - j1) * 32;
-  // x[q] is exactly 0 for q >= nb.  The store into A is steered by an address select, not a branch
-  // (32 predicated branches here made hipcc spill 600+ registers).
-#pragma unroll
-  for (int q = 0; q < 32; ++q) {
-    double* dst = (q < nb) ? (arow + q) : (prow + q);
-    *dst = x[q];
-    prow[q] = x[q];
-  }
-}
-
-__global__ void k_chol_store_diag(double* __restrict__ A, int n, int j0, int nb, const double* __restrict__ Ld) {
-  for (int i = threadIdx.x; i < 32 * 32; i += blockDim.x) {
-    const int r = i >> 5, c = i & 31;
-    if (r < nb && c <= r) A[(size_t)(j0 + r) * n + j0 + c] = Ld[i];
-  }
-}
-
-__global__ __launch_bounds__(256) void k_chol_update(double* __restrict__ A, int n, int nrows, int j1,
-                                                     const double* __restrict__ panel, int j0, int nb,
-                                                     const double* __restrict__ Ld) {
-  constexpr int LDP = 34;
-  __shared__ double sI[64 * LDP], sJ[64 * LDP];
-  const int ti = blockIdx.y, tj = blockIdx.x, tid = threadIdx.x;
-  if (ti == 0 && tj == 0) {
-    for (int i = tid; i < 32 * 32; i += 256) {
-      const int r = i >> 5, c = i & 31;
-      if (r < nb && c <= r) A[(size_t)(j0 + r) * n + j0 + c] = Ld[i];
+    for (int t = 0; t < 2; ++t) {
+      const double b = sLi[(t * 16 + r16) * LDI + k0 + kq];
+      acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[t], 0, 0, 0);
     }
   }
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int row = rbase + kq + 4 * i, col = t * 16 + r16;
+      if (row < nrows) {
+        const double v = (col < nb) ? acc[t][i] : 0.0;
+        if (col < nb) A[(size_t)row * n + j0 + col] = v;
+        panel[(size_t)(row - j1) * 32 + col] = v;
+      }
+    }
+}
+
+// Rank-32 update of the trailing lower 64x64 tiles on v_mfma_f64_16x16x4_f64 (panel rows staged in LDS,
+// row stride 34 doubles = conflict-free ds_read_b64).  Look-ahead: the workgroup of tile (0,0) then factors
+// the NEXT diagonal block (the top-left 32x32 of its tile) in wavefront 0 and publishes L / 1/diag for the
+// next panel kernel, so the serial factorisation chain never waits for a kernel of its own.
+__global__ __launch_bounds__(256) void k_chol_update(double* __restrict__ A, int n, int nrows, int j1,
+                                                     const double* __restrict__ panel, double* __restrict__ Ld,
+                                                     double* __restrict__ rd, int* __restrict__ fail) {
+  constexpr int LDP = 34;
+  __shared__ double sI[64 * LDP], sJ[64 * LDP];
+  __shared__ double sL[32 * 33], srd[32], scol[128];
+  const int ti = blockIdx.y, tj = blockIdx.x, tid = threadIdx.x;
   if (tj > ti) return;
   const int lane = tid & 63, w = tid >> 6;
   const int rem_r = nrows - j1, rem_c = n - j1;
@@ -166,13 +218,43 @@ __global__ __launch_bounds__(256) void k_chol_update(double* __restrict__ A, int
       acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[t], 0, 0, 0);
     }
   }
+  const bool crit = (ti == 0 && tj == 0);
+  const int nbn = rem_c < 32 ? rem_c : 32;        // size of the next diagonal block (rem_c >= 1 here)
 #pragma unroll
   for (int t = 0; t < 4; ++t)
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      const int gr = I0 + w * 16 + rq + 4 * i, gcol = J0 + t * 16 + col16;
-      if (gr < rem_r && gcol < rem_c && gcol <= gr) A[(size_t)(j1 + gr) * n + j1 + gcol] = cv[t][i] - acc[t][i];
+      const int lr = w * 16 + rq + 4 * i, lc = t * 16 + col16;      // position inside the tile
+      const int gr = I0 + lr, gcol = J0 + lc;
+      const double v = cv[t][i] - acc[t][i];
+      const bool inside = gr < rem_r && gcol < rem_c && gcol <= gr;
+      // the next diagonal block (top-left nbn x nbn of tile (0,0)) goes to LDS for the in-wave factorisation;
+      // a short last block leaves the bordered right-hand-side row (lr >= nbn) on the normal path
+      if (crit && lr < nbn && lc < nbn) { if (lc <= lr) sL[lr * 33 + lc] = v; }
+      else if (inside) A[(size_t)(j1 + gr) * n + j1 + gcol] = v;
     }
+  if (!crit) return;
+  __syncthreads();
+  if (w != 0) return;
+  {
+    const int i = lane & 31, h = lane >> 5;
+    double a[16];
+#pragma unroll
+    for (int t = 0; t < 16; ++t) {
+      const int q = 2 * t + h;
+      a[t] = (q <= i) ? ((i < nbn && q < nbn) ? sL[i * 33 + q] : ((q == i) ? 1.0 : 0.0)) : 0.0;
+    }
+    const bool ok = wave_chol32(a, lane, sL, srd, scol);
+    if (!ok && lane == 0) *fail = 1;
+    for (int e = lane; e < 32 * 32; e += 64) {
+      const int r = e >> 5, c = e & 31;
+      if (r < nbn && c <= r) A[(size_t)(j1 + r) * n + j1 + c] = sL[r * 33 + c];
+    }
+    double* sLi = sI;                                  // the panel staging area is free again
+    wave_inv32(sL, srd, lane, sLi);
+    for (int e = lane; e < 32 * 32; e += 64) Ld[e] = sLi[(e >> 5) * 33 + (e & 31)];     // Ld carries L^-1
+    if (lane < 32) rd[lane] = srd[lane];
+  }
 }
 
 // ------------------------------------------------------------------------------------ diagonal-block inverses
@@ -197,44 +279,67 @@ __global__ __launch_bounds__(64) void k_inv64(const double* __restrict__ L, int 
     out[r * 64 + t] = x[r];                      // coalesced over t
   }
 }
-// 128-block = [A 0; B C]:  inverse = [Ai 0; -Ci B Ai, Ci].   T = B Ai
-__global__ __launch_bounds__(256) void k_inv_merge_T(const double* __restrict__ L, int n, const double* __restrict__ inv64,
-                                                     double* __restrict__ tmp) {
-  const int b = blockIdx.x, r0 = b * 128;
-  const double* Ai = inv64 + (size_t)(2 * b) * 64 * 64;
-  for (int e = threadIdx.x; e < 64 * 64; e += 256) {
-    const int r = e >> 6, c = e & 63;
-    double s = 0.0;
-    if (r0 + 64 + r < n) {
-      const double* brow = L + (size_t)(r0 + 64 + r) * n + r0;
-      for (int k = c; k < 64; ++k) s += brow[k] * Ai[k * 64 + c];      // Ai lower: k >= c
-    }
-    tmp[(size_t)b * 64 * 64 + e] = s;
-  }
-}
-__global__ __launch_bounds__(256) void k_inv_merge_M(int n, const double* __restrict__ inv64, const double* __restrict__ tmp,
-                                                     double* __restrict__ Dinv, double* __restrict__ DinvT) {
-  const int b = blockIdx.x;
+
+// 128-block = [A 0; B C]:  inverse = [Ai 0; -Ci B Ai, Ci].  One workgroup per block; both 64x64x64 products
+// on v_mfma_f64_16x16x4_f64 (wave w owns rows 16 w .. 16 w + 15), T = B Ai kept in LDS between them.
+__global__ __launch_bounds__(256) void k_inv_merge(const double* __restrict__ L, int n, const double* __restrict__ inv64,
+                                                   double* __restrict__ Dinv, double* __restrict__ DinvT) {
+  constexpr int LDT = 66;
+  __shared__ double sT[64 * LDT];
+  const int b = blockIdx.x, r0 = b * 128, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const double* Ai = inv64 + (size_t)(2 * b) * 64 * 64;
   const double* Ci = inv64 + (size_t)(2 * b + 1) * 64 * 64;
-  const double* T = tmp + (size_t)b * 64 * 64;
   double* D = Dinv + (size_t)b * 128 * 128;
   double* Dt = DinvT + (size_t)b * 128 * 128;
-  for (int e = threadIdx.x; e < 128 * 128; e += 256) {
-    const int r = e >> 7, c = e & 127;
-    double v = 0.0;
-    if (r < 64) { if (c < 64) v = Ai[r * 64 + c]; }
-    else if (c >= 64) v = Ci[(r - 64) * 64 + (c - 64)];
-    else {
-      const int rr = r - 64;
-      double s = 0.0;
-      for (int k = 0; k <= rr; ++k) s += Ci[rr * 64 + k] * T[k * 64 + c];   // Ci lower: k <= rr
-      v = -s;
+  const int r16 = lane & 15, kq = lane >> 4;
+  // T = B Ai : A operand = B[row][k] (rows r0+64.., cols r0..r0+63 of L), B operand = Ai[k][col]
+  v4d acc[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) acc[t] = (v4d){0.0, 0.0, 0.0, 0.0};
+  const int brow = r0 + 64 + w * 16 + r16;
+  const double* bptr = L + (size_t)brow * n + r0;
+  const bool bok = brow < n;
+  for (int k0 = 0; k0 < 64; k0 += 4) {
+    const double a = bok ? bptr[k0 + kq] : 0.0;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const double bb = Ai[(k0 + kq) * 64 + t * 16 + r16];
+      acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bb, acc[t], 0, 0, 0);
     }
-    D[r * 128 + c] = v;
-    Dt[c * 128 + r] = v;
   }
-  (void)n;
+#pragma unroll
+  for (int t = 0; t < 4; ++t)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) sT[(w * 16 + kq + 4 * i) * LDT + t * 16 + r16] = acc[t][i];
+  __syncthreads();
+  // M = -Ci T : A operand = Ci[row][k], B operand = T[k][col]
+#pragma unroll
+  for (int t = 0; t < 4; ++t) acc[t] = (v4d){0.0, 0.0, 0.0, 0.0};
+  for (int k0 = 0; k0 < 64; k0 += 4) {
+    const double a = Ci[(w * 16 + r16) * 64 + k0 + kq];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const double bb = sT[(k0 + kq) * LDT + t * 16 + r16];
+      acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bb, acc[t], 0, 0, 0);
+    }
+  }
+#pragma unroll
+  for (int t = 0; t < 4; ++t)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int r = 64 + w * 16 + kq + 4 * i, c = t * 16 + r16;
+      const double v = -acc[t][i];
+      D[r * 128 + c] = v;
+      Dt[c * 128 + r] = v;
+    }
+  // the two diagonal quadrants and the zero quadrant
+  for (int e = tid; e < 64 * 64; e += 256) {
+    const int r = e >> 6, c = e & 63;
+    const double va = Ai[e], vc = Ci[e];
+    D[r * 128 + c] = va;               Dt[c * 128 + r] = va;
+    D[(64 + r) * 128 + 64 + c] = vc;   Dt[(64 + c) * 128 + 64 + r] = vc;
+    D[r * 128 + 64 + c] = 0.0;         Dt[(64 + c) * 128 + r] = 0.0;
+  }
 }
 
 // ------------------------------------------------------------------------------------ triangular solves
@@ -287,25 +392,22 @@ __global__ __launch_bounds__(256) void k_trsv_step(const double* __restrict__ L,
 
 // ------------------------------------------------------------------------------------ host
 int dense_cholesky(sfm_ctx* h, double* A, int n, int nrows, const DenseWs& w) {
+  hipLaunchKernelGGL(k_chol_diag, dim3(1), dim3(64), 0, h->stream, A, n, 0, w.Ld, w.rd, w.flag);
   for (int j0 = 0; j0 < n; j0 += 32) {
     const int nb = (n - j0) < 32 ? (n - j0) : 32;
     const int j1 = j0 + nb;
     const int below = nrows - j1;
-    const unsigned g = below > 0 ? cdiv(below, 256) : 1;
-    hipLaunchKernelGGL(k_chol_panel, dim3(g), dim3(256), 0, h->stream, A, n, nrows, j0, w.panel, w.Ld, w.flag);
-    if (below > 0) {
+    if (below <= 0) break;
+    hipLaunchKernelGGL(k_chol_panel, dim3(cdiv(below, 64)), dim3(256), 0, h->stream, A, n, nrows, j0, w.panel, w.Ld);
+    if (j1 < n) {         // trailing columns exist: update them and factor the next diagonal block
       const unsigned T = cdiv(below, 64);
-      hipLaunchKernelGGL(k_chol_update, dim3(T, T), dim3(256), 0, h->stream, A, n, nrows, j1, w.panel, j0, nb, w.Ld);
-    } else {
-      hipLaunchKernelGGL(k_chol_store_diag, dim3(1), dim3(256), 0, h->stream, A, n, j0, nb, w.Ld);
+      hipLaunchKernelGGL(k_chol_update, dim3(T, T), dim3(256), 0, h->stream, A, n, nrows, j1, w.panel, w.Ld, w.rd, w.flag);
     }
   }
-  // diagonal-block inverses for the triangular solves
-  const unsigned nb64 = cdiv(n, 64), nb128 = cdiv(n, 128);
+  // inverses of the 128x128 diagonal blocks of L for the triangular solves
+  const unsigned nb128 = cdiv(n, 128);
   hipLaunchKernelGGL(k_inv64, dim3(2 * nb128), dim3(64), 0, h->stream, A, n, w.inv64);
-  hipLaunchKernelGGL(k_inv_merge_T, dim3(nb128), dim3(256), 0, h->stream, A, n, w.inv64, w.tmp);
-  hipLaunchKernelGGL(k_inv_merge_M, dim3(nb128), dim3(256), 0, h->stream, n, w.inv64, w.tmp, w.Dinv, w.DinvT);
-  (void)nb64;
+  hipLaunchKernelGGL(k_inv_merge, dim3(nb128), dim3(256), 0, h->stream, A, n, w.inv64, w.Dinv, w.DinvT);
   SFM_LAUNCH_CHECK(h, "dense_cholesky");
   return SFM_OK;
 }
@@ -351,8 +453,7 @@ extern "C" int sfm_dense_trsv(sfm_handle h, const double* l, int32_t n, double* 
   double* xout = base + dense_ws_doubles(n);
   const unsigned nb128 = cdiv(n, 128);
   hipLaunchKernelGGL(k_inv64, dim3(2 * nb128), dim3(64), 0, h->stream, l, n, w.inv64);
-  hipLaunchKernelGGL(k_inv_merge_T, dim3(nb128), dim3(256), 0, h->stream, l, n, w.inv64, w.tmp);
-  hipLaunchKernelGGL(k_inv_merge_M, dim3(nb128), dim3(256), 0, h->stream, n, w.inv64, w.tmp, w.Dinv, w.DinvT);
+  hipLaunchKernelGGL(k_inv_merge, dim3(nb128), dim3(256), 0, h->stream, l, n, w.inv64, w.Dinv, w.DinvT);
   int rc = dense_trsv(h, l, n, w, b, xout, transpose ? 1 : 0);
   if (rc == SFM_OK) {
     SFM_HIP(h, hipMemcpyAsync(b, xout, (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, h->stream));

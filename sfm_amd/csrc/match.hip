@@ -20,6 +20,10 @@ typedef int v16i __attribute__((ext_vector_type(16)));
 #define KEY_SENTINEL 0x7FFFFF00
 #define D2_MAX_VALID 8323200   // 128 * 255^2
 
+// Correctly rounded float32 square root (what sqrtf / OpenCV's std::sqrt give on the CPU): the fp64 root
+// (correctly rounded, 53 >= 2*24+2 bits) rounded once to float32.  __fsqrt_rn is NOT correctly rounded here.
+__device__ __forceinline__ float sqrt_rn_f32(float x) { return (float)sqrt((double)x); }
+
 struct Cand { float d; int i; };   // distance (already sqrtf'ed / popcount), train index; i < 0 = empty
 
 __device__ __forceinline__ bool cand_less(float d, int i, float d2, int i2) {
@@ -198,8 +202,8 @@ __global__ __launch_bounds__(256) void k_knn2_u8(const uint8_t* __restrict__ q, 
     const int64_t qi = q0 + qb * 32 + l31;
     if (half == 0 && qi < nq) {
       Cand* o = part + ((int64_t)split * nq + qi) * 2;
-      o[0].d = b1i >= 0 ? __fsqrt_rn(b1d) : 0.0f; o[0].i = b1i;
-      o[1].d = b2i >= 0 ? __fsqrt_rn(b2d) : 0.0f; o[1].i = b2i;
+      o[0].d = b1i >= 0 ? sqrt_rn_f32(b1d) : 0.0f; o[0].i = b1i;
+      o[1].d = b2i >= 0 ? sqrt_rn_f32(b2d) : 0.0f; o[1].i = b2i;
     }
   }
 }
@@ -241,7 +245,7 @@ __global__ __launch_bounds__(256) void k_knn2_valu(const uint32_t* __restrict__ 
           const float prod = diff * diff;      // plain operators: the pragma is lexical
           acc = acc + prod;
         }
-        dist = __fsqrt_rn(acc);
+        dist = sqrt_rn_f32(acc);
       } else {
         int pc = 0;
 #pragma unroll
