@@ -125,6 +125,16 @@ def main():
                     "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
                     "bytes_per_launch": bytes_per_obs * be.N, "avg_us": round(per_launch_s * 1e6, 2),
                     "launches": lin_cnt}
+        # HBM bytes per launch from the PMC counters (rocprofv3 cannot run inside this process): taken from
+        # the committed summary of the same workload, collected and corrected as MI355X_MICROARCH.md prescribes
+        try:
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_summary.json")))
+            wl = pmc["workload"]
+            if world == 1 and (wl["cams"], wl["pts"], wl["obs"], wl["cam_dim"]) == (C, P, n_obs_total, d):
+                roofline["traffic"] = pmc["k_lin_obs"]["hbm_bytes_per_launch"]
+                roofline["traffic_source"] = "profiles/r01_pmc_summary.json (FETCH_SIZE x2 + WRITE_SIZE, separate --pmc passes)"
+        except (OSError, KeyError, ValueError):
+            pass
     kernels = {k: {"ms_total": round(v[0], 3), "launches": v[1],
                    "share": round(v[0] / (elapsed * 1e3), 4)} for k, v in prof.items() if v[1] > 0}
 

@@ -27,6 +27,15 @@ def lib():
         l.bao_get.argtypes = [vp, vp]
         l.bao_get_step.argtypes = [vp, vp, vp]
         l.bao_threads.restype = i32
+        l.bao_set_threads.argtypes = [i32]
+        # a GPU box shows every hardware thread but grants a share of them (16 per GPU): oversubscribing
+        # OpenMP there runs the baseline slower than it deserves
+        import os
+        try:
+            avail = len(os.sched_getaffinity(0))
+        except AttributeError:
+            avail = os.cpu_count() or 1
+        l.bao_set_threads(max(1, min(avail, int(os.environ.get("SFM_ORACLE_THREADS", "16")))))
         l.mo_knn2_u8.argtypes = [vp, i64, vp, i64, i32, vp, vp, vp, vp]
         _lib = l
     return _lib

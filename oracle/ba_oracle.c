@@ -426,6 +426,13 @@ int bao_trf(bao* b, double* x, double ftol, double xtol, double gtol, int max_nf
 
 void bao_get(bao* b, double* out4) { out4[0] = b->cost; out4[1] = b->gnorm; out4[2] = b->ginf; out4[3] = b->hdiag; }
 void bao_get_step(bao* b, double* pc, double* pp) { memcpy(pc, b->pc, (size_t)b->n * 8); memcpy(pp, b->pp, (size_t)b->P * 24); }
+void bao_set_threads(int n) {
+#ifdef _OPENMP
+  if (n > 0) omp_set_num_threads(n);
+#else
+  (void)n;
+#endif
+}
 int bao_threads(void) {
 #ifdef _OPENMP
   return omp_get_max_threads();
