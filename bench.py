@@ -61,20 +61,28 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    # SFM_FORCE_DIST=1 runs the RCCL code path (process group, all-reduces of the workspace views) with a
+    # single rank too - used to rehearse the multi-GPU path on a one-GPU box
+    use_dist = world > 1 or os.environ.get("SFM_FORCE_DIST") == "1"
+    if use_dist:
+        if "RANK" not in os.environ:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29577")
+            os.environ.update(RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         comm = DistComm()
+        comm.force = True
     else:
         comm = LocalComm()
 
     def barrier_sync():
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
     def max_over_ranks(v):
-        if world == 1:
+        if not use_dist:
             return v
         t = torch.tensor([v], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -202,7 +210,7 @@ def main():
             "roofline": roofline, "cpu_baseline": cpu_baseline, "matcher": matcher,
         }
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

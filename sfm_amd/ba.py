@@ -92,7 +92,7 @@ class GpuBA:
     def linearize(self):
         L = self.lay
         self.h.call("sfm_ba_linearize", self._pp, C.c_void_p(self.x.data_ptr()))
-        if self.comm.world_size > 1:
+        if self.comm.world_size > 1 or getattr(self.comm, 'force', False):
             self.comm.allreduce_sum(self.view(L.reduce_lin_off, L.reduce_lin_count))
             self.comm.allreduce_max(self.view(L.gmax_off, 2))
         self.h.call("sfm_ba_finish_linearize", self._pp)
@@ -103,10 +103,10 @@ class GpuBA:
         L = self.lay
         wq = 1 if want_q else 0
         self.h.call("sfm_ba_schur_build", self._pp, C.c_double(alpha))
-        if self.comm.world_size > 1:
+        if self.comm.world_size > 1 or getattr(self.comm, 'force', False):
             self.comm.allreduce_sum(self.view(L.reduce_S_off, L.reduce_S_count))
         self.h.call("sfm_ba_schur_solve", self._pp, C.c_double(alpha), wq)
-        if self.comm.world_size > 1:
+        if self.comm.world_size > 1 or getattr(self.comm, 'force', False):
             self.comm.allreduce_sum(self.view(L.reduce_q_off, L.reduce_q_count))
         self.h.call("sfm_ba_finish_solve", self._pp, wq)
         s = self.scalars()
@@ -119,7 +119,7 @@ class GpuBA:
         L = self.lay
         xp, xn = C.c_void_p(self.x.data_ptr()), C.c_void_p(self.x_new.data_ptr())
         self.h.call("sfm_ba_step", self._pp, xp, C.c_double(scale), xn)
-        if self.comm.world_size > 1:
+        if self.comm.world_size > 1 or getattr(self.comm, 'force', False):
             self.comm.allreduce_sum(self.view(L.reduce_step_off, L.reduce_step_count))
         self.h.call("sfm_ba_finish_step", self._pp, xp, C.c_double(scale), xn)
         s = self.scalars()
@@ -135,7 +135,7 @@ class GpuBA:
         x = self.x if x is None else x
         self.h.call("sfm_ba_cost", self._pp, C.c_void_p(x.data_ptr()))
         red = self.view(L.reduce_step_off, L.reduce_step_count)
-        if self.comm.world_size > 1:
+        if self.comm.world_size > 1 or getattr(self.comm, 'force', False):
             self.comm.allreduce_sum(red)
         return float(red[2].item())
 
