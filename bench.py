@@ -67,7 +67,10 @@ def main():
     if use_dist:
         if "RANK" not in os.environ:
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-            os.environ.setdefault("MASTER_PORT", "29577")
+            import socket
+            with socket.socket() as sk:
+                sk.bind(("127.0.0.1", 0))
+                os.environ.setdefault("MASTER_PORT", str(sk.getsockname()[1]))
             os.environ.update(RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         comm = DistComm()

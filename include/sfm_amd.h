@@ -121,7 +121,8 @@ typedef struct {
 /* Byte offsets into the workspace of the regions the host reads or all-reduces. */
 typedef struct {
   int64_t total_bytes;
-  int64_t rec_off, rec_stride;      /* per observation: Jc~ [2][cam_dim], Jp~ [2][3], f~ [2] (robust-scaled), doubles */
+  int64_t rec_off, rec_stride;      /* per observation: Jc~ [2][cam_dim] (robust-scaled), doubles; stride in bytes */
+  int64_t recB_off;                 /* per observation: Jp~ [2][3], f~ [2] (8 doubles) */
   int64_t B_off, gc_off;            /* [n_cams][cam_dim][cam_dim], [n_cams][cam_dim]   (this rank's partial sums) */
   int64_t Cp_off, gp_off;           /* [n_pts][6] (xx,xy,xz,yy,yz,zz), [n_pts][3] */
   int64_t reduce_lin_off, reduce_lin_count;     /* doubles: [gc copy (n) | cost | ||gp||^2 | diag(B) (n)], n = n_cams*cam_dim  SUM */

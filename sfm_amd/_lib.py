@@ -32,7 +32,7 @@ class BAProblem(C.Structure):
 
 class BALayout(C.Structure):
     _fields_ = [(n, i64) for n in (
-        "total_bytes", "rec_off", "rec_stride", "B_off", "gc_off", "Cp_off", "gp_off",
+        "total_bytes", "rec_off", "rec_stride", "recB_off", "B_off", "gc_off", "Cp_off", "gp_off",
         "reduce_lin_off", "reduce_lin_count", "gmax_off", "reduce_S_off", "reduce_S_count",
         "reduce_q_off", "reduce_q_count", "reduce_step_off", "reduce_step_count",
         "pc_off", "pp_off", "scalars_off", "G_off")]

@@ -6,7 +6,8 @@
 // order of operations matters (Rodrigues coefficients, Huber scaling).
 //
 // Data layout in HBM (all inside the caller's workspace, see ba_layout()):
-//   rec    [N][2D+8]  per observation, point-major: Jc~ rows (2xD), Jp~ rows (2x3), f~ (2)
+//   recA   [N][2D]    per observation, point-major: Jc~ rows (2xD)
+//   recB   [N][8]     per observation: Jp~ rows (2x3), f~ (2)
 //   G      [N][3][D]  per observation, per alpha: W_k L_j^-T  (L_j L_j^T = C_j + alpha I)
 //   S | r  [(n+1)][n] reduced camera system with its right-hand side as a bordered row
 // Observations of one point (a track) are contiguous; cameras are reached through cam_obs.
@@ -16,12 +17,12 @@ typedef double v4d __attribute__((ext_vector_type(4)));
 
 #define EPS_D 2.220446049250313e-16
 #define SQRT_EPS_D 1.4901161193847656e-08
-#define CAMPRE 44   // R[9] dR[27] t[3] fx fy cx cy pad
+#define CAMPRE 16   // r[3] t[3] fx fy cx cy  a b a1 b1 (Rodrigues coefficients)  |r|^2 pad
 
 // ------------------------------------------------------------------------------------ layout
 struct Lay {   // offsets in doubles
-  int64_t rec, campre, campre2, B, gc, Cp, gp, Linv, e, v, tmp3, G, red_lin, gmax, red_S, red_q,
-      red_step, pc, pp, y, tvec, scalars, part_obs, part_pt, part_x, cost_reg, regrec, dense, sch_part, cch_part, total;
+  int64_t recA, recB, campre, campre2, B, gc, Cp, gp, Linv, e, v, tmp3, G, red_lin, gmax, red_S, red_q,
+      red_step, pc, pp, y, tvec, scalars, part_obs, part_pt, part_x, cost_reg, regrec, dense, sch_part, cch_part, cbl_part, total;
   int64_t nblk_obs, nblk_pt;
 };
 
@@ -31,7 +32,8 @@ static Lay ba_layout(int64_t C, int64_t P, int64_t N, int64_t D, int64_t n_items
   auto take = [&](int64_t cnt) { int64_t r = o; o = align_up(o + cnt, 32); return r; };
   L.nblk_obs = (N + 255) / 256;
   L.nblk_pt = (P + 255) / 256;
-  L.rec = take(N * (2 * D + 8));
+  L.recA = take(N * 2 * D);
+  L.recB = take(N * 8);
   L.campre = take(C * CAMPRE);
   L.campre2 = take(C * CAMPRE);
   L.B = take(C * D * D);
@@ -61,6 +63,7 @@ static Lay ba_layout(int64_t C, int64_t P, int64_t N, int64_t D, int64_t n_items
   L.dense = take(dense_ws_doubles((int)n));
   L.sch_part = take(n_items * D * D);
   L.cch_part = take(n_cchunks * 16);
+  L.cbl_part = take(n_cchunks * (D * D + D));
   L.total = o;
   return L;
 }
@@ -72,7 +75,8 @@ extern "C" int sfm_ba_get_layout(int32_t n_cams, int32_t n_pts, int64_t n_obs, i
   Lay L = ba_layout(n_cams, n_pts, n_obs, cam_dim, n_items, n_cchunks);
   int64_t n = (int64_t)n_cams * cam_dim;
   out->total_bytes = L.total * 8;
-  out->rec_off = L.rec * 8; out->rec_stride = (2 * cam_dim + 8) * 8;
+  out->rec_off = L.recA * 8; out->rec_stride = 2 * cam_dim * 8;
+  out->recB_off = L.recB * 8;
   out->B_off = L.B * 8; out->gc_off = L.gc * 8;
   out->Cp_off = L.Cp * 8; out->gp_off = L.gp * 8;
   out->reduce_lin_off = L.red_lin * 8; out->reduce_lin_count = 2 * n + 2;
@@ -139,15 +143,17 @@ __device__ __forceinline__ void mat3_mul(const double* A, const double* Bm, doub
 }
 
 // ------------------------------------------------------------------------------------ per-camera precompute
-// R = I + a[r]x + b[r]x^2 and dR/dr_i (same series/closed-form split as the oracle's _rod_coeffs).
+// Rodrigues coefficients of R = I + a[r]x + b[r]x^2 and of dR/dr_i (same series / closed-form split as the
+// oracle's _rod_coeffs).  Only 14 doubles per camera are kept; R X and (dR/dr_i) X are rebuilt per observation
+// from cross products (cam_apply below) - gathering a 3x3 R and three 3x3 dR per observation cost more L1/TA
+// traffic than the kernel's whole HBM stream.
 template <int D>
 __global__ void k_campre(const double* __restrict__ cams, int C, double fx0, double fy0, double cx0,
                          double cy0, double* __restrict__ out) {
   int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= C) return;
   const double* p = cams + (size_t)c * D;
-  double r[3] = {p[0], p[1], p[2]};
-  double th2 = r[0] * r[0] + r[1] * r[1] + r[2] * r[2];
+  const double th2 = p[0] * p[0] + p[1] * p[1] + p[2] * p[2];
   double a, b, a1, b1;
   if (th2 < 1e-4) {
     double z = th2;
@@ -163,59 +169,58 @@ __global__ void k_campre(const double* __restrict__ cams, int C, double fx0, dou
     a1 = (t * co - s) / (th2 * t);
     b1 = (t * s - 2.0 * (1.0 - co)) / (th2 * th2);
   }
-  double S[9] = {0, -r[2], r[1], r[2], 0, -r[0], -r[1], r[0], 0};
-  double S2[9];
-  mat3_mul(S, S, S2);
   double* o = out + (size_t)c * CAMPRE;
 #pragma unroll
-  for (int i = 0; i < 9; ++i) o[i] = ((i % 4 == 0) ? 1.0 : 0.0) + a * S[i] + b * S2[i];
-#pragma unroll
-  for (int i = 0; i < 3; ++i) {
-    double e[3] = {0, 0, 0};
-    e[i] = 1.0;
-    double E[9] = {0, -e[2], e[1], e[2], 0, -e[0], -e[1], e[0], 0};
-    double ES[9], SE[9];
-    mat3_mul(E, S, ES);
-    mat3_mul(S, E, SE);
-#pragma unroll
-    for (int q = 0; q < 9; ++q)
-      o[9 + i * 9 + q] = a * E[q] + b * (ES[q] + SE[q]) + (a1 * r[i]) * S[q] + (b1 * r[i]) * S2[q];
-  }
-  o[36] = p[3]; o[37] = p[4]; o[38] = p[5];
-  if (D == 10) { o[39] = p[6]; o[40] = p[7]; o[41] = p[8]; o[42] = p[9]; }
-  else { o[39] = fx0; o[40] = fy0; o[41] = cx0; o[42] = cy0; }
-  o[43] = 0.0;
+  for (int i = 0; i < 6; ++i) o[i] = p[i];
+  if (D == 10) { o[6] = p[6]; o[7] = p[7]; o[8] = p[8]; o[9] = p[9]; }
+  else { o[6] = fx0; o[7] = fy0; o[8] = cx0; o[9] = cy0; }
+  o[10] = a; o[11] = b; o[12] = a1; o[13] = b1; o[14] = th2; o[15] = 0.0;
+}
+
+// Y = R X + t  with  R X = X + a (r x X) + b (r x (r x X))
+__device__ __forceinline__ void cam_project(const double* __restrict__ cp, double X0, double X1, double X2,
+                                            double& Y0, double& Y1, double& Y2) {
+  const double r0 = cp[0], r1 = cp[1], r2 = cp[2], a = cp[10], b = cp[11];
+  const double c0 = r1 * X2 - r2 * X1, c1 = r2 * X0 - r0 * X2, c2 = r0 * X1 - r1 * X0;       // r x X
+  const double e0 = r1 * c2 - r2 * c1, e1 = r2 * c0 - r0 * c2, e2 = r0 * c1 - r1 * c0;       // r x (r x X)
+  Y0 = X0 + a * c0 + b * e0 + cp[3];
+  Y1 = X1 + a * c1 + b * e1 + cp[4];
+  Y2 = X2 + a * c2 + b * e2 + cp[5];
 }
 
 // ------------------------------------------------------------------------------------ linearise: per observation
 // One thread per observation (point-major).  Residual (sfm_reconstruction.py:453-470,486), analytic
-// 2x(D+3) Jacobian, Huber row scaling; the record is transposed through LDS so
-// the 2D+8 doubles of 256 observations leave the CU as one contiguous, fully coalesced stream.
+// 2x(D+3) Jacobian, Huber row scaling.  The two record arrays are transposed through
+// LDS one after the other (43 KB instead of 59 KB: 3 workgroups per CU) so the doubles of 256 observations
+// leave the CU as contiguous, fully coalesced streams.
 template <int D>
 __global__ __launch_bounds__(256) void k_lin_obs(int64_t N, const int* __restrict__ cam_idx,
                                                  const int* __restrict__ pt_idx,
                                                  const double* __restrict__ uv,
                                                  const double* __restrict__ pts,
                                                  const double* __restrict__ campre,
-                                                 double* __restrict__ rec, double* __restrict__ part) {
-  constexpr int REC = 2 * D + 8, LDR = REC + 1;
-  __shared__ double s_rec[256 * LDR];
+                                                 double* __restrict__ recA, double* __restrict__ recB,
+                                                 double* __restrict__ part) {
+  constexpr int WA = 2 * D, LDA = WA + 1, WB = 8, LDB = WB + 1;
+  __shared__ double s_rec[256 * LDA];
   __shared__ double s_red[4];
   const int tid = threadIdx.x;
   const int64_t k0 = (int64_t)blockIdx.x * 256;
   const int64_t k = k0 + tid;
   double cost = 0.0;
+  double jb[8];
+#pragma unroll
+  for (int q = 0; q < 8; ++q) jb[q] = 0.0;
   if (k < N) {
     const int c = cam_idx[k], j = pt_idx[k];
     const double* cp = campre + (size_t)c * CAMPRE;
     const double X0 = pts[3 * (size_t)j], X1 = pts[3 * (size_t)j + 1], X2 = pts[3 * (size_t)j + 2];
-    double R[9];
-#pragma unroll
-    for (int i = 0; i < 9; ++i) R[i] = cp[i];
-    const double Y0 = R[0] * X0 + R[1] * X1 + R[2] * X2 + cp[36];
-    const double Y1 = R[3] * X0 + R[4] * X1 + R[5] * X2 + cp[37];
-    const double Y2 = R[6] * X0 + R[7] * X1 + R[8] * X2 + cp[38];
-    const double fx = cp[39], fy = cp[40], cx = cp[41], cy = cp[42];
+    const double r0 = cp[0], r1 = cp[1], r2 = cp[2];
+    const double fx = cp[6], fy = cp[7], cx = cp[8], cy = cp[9];
+    const double a = cp[10], b = cp[11], a1 = cp[12], b1 = cp[13], th2 = cp[14];
+    const double c0 = r1 * X2 - r2 * X1, c1 = r2 * X0 - r0 * X2, c2 = r0 * X1 - r1 * X0;       // r x X
+    const double e0 = r1 * c2 - r2 * c1, e1 = r2 * c0 - r0 * c2, e2 = r0 * c1 - r1 * c0;       // r x (r x X)
+    const double Y0 = X0 + a * c0 + b * e0 + cp[3], Y1 = X1 + a * c1 + b * e1 + cp[4], Y2 = X2 + a * c2 + b * e2 + cp[5];
     const double iz = 1.0 / Y2, xn = Y0 * iz, yn = Y1 * iz;
     const double f0 = fx * xn + cx - uv[2 * k], f1 = fy * yn + cy - uv[2 * k + 1];
     double s0, s1, ft0, ft1;
@@ -223,15 +228,27 @@ __global__ __launch_bounds__(256) void k_lin_obs(int64_t N, const int* __restric
     // Pi = d(u,v)/d(x,y,z), already multiplied by the robust row scale
     const double p00 = s0 * fx * iz, p02 = -s0 * fx * xn * iz;
     const double p11 = s1 * fy * iz, p12 = -s1 * fy * yn * iz;
-    double* my = &s_rec[tid * LDR];
-#pragma unroll
-    for (int i = 0; i < 3; ++i) {
-      const double* dR = cp + 9 + i * 9;
-      const double d0 = dR[0] * X0 + dR[1] * X1 + dR[2] * X2;
-      const double d1 = dR[3] * X0 + dR[4] * X1 + dR[5] * X2;
-      const double d2 = dR[6] * X0 + dR[7] * X1 + dR[8] * X2;
-      my[i] = p00 * d0 + p02 * d2;
-      my[D + i] = p11 * d1 + p12 * d2;
+    double* my = &s_rec[tid * LDA];
+    // (dR/dr_i) X = a (e_i x X) + b (r X_i + e_i (r.X) - 2 r_i X) + r_i (a1 (r x X) + b1 (r x (r x X)))
+    const double rx = r0 * X0 + r1 * X1 + r2 * X2;
+    const double w0 = a1 * c0 + b1 * e0, w1 = a1 * c1 + b1 * e1, w2 = a1 * c2 + b1 * e2;
+    {
+      const double d0 = b * (r0 * X0 + rx - 2.0 * r0 * X0) + r0 * w0;
+      const double d1 = a * (-X2) + b * (r1 * X0 - 2.0 * r0 * X1) + r0 * w1;
+      const double d2 = a * (X1) + b * (r2 * X0 - 2.0 * r0 * X2) + r0 * w2;
+      my[0] = p00 * d0 + p02 * d2; my[D] = p11 * d1 + p12 * d2;
+    }
+    {
+      const double d0 = a * (X2) + b * (r0 * X1 - 2.0 * r1 * X0) + r1 * w0;
+      const double d1 = b * (r1 * X1 + rx - 2.0 * r1 * X1) + r1 * w1;
+      const double d2 = a * (-X0) + b * (r2 * X1 - 2.0 * r1 * X2) + r1 * w2;
+      my[1] = p00 * d0 + p02 * d2; my[D + 1] = p11 * d1 + p12 * d2;
+    }
+    {
+      const double d0 = a * (-X1) + b * (r0 * X2 - 2.0 * r2 * X0) + r2 * w0;
+      const double d1 = a * (X0) + b * (r1 * X2 - 2.0 * r2 * X1) + r2 * w1;
+      const double d2 = b * (r2 * X2 + rx - 2.0 * r2 * X2) + r2 * w2;
+      my[2] = p00 * d0 + p02 * d2; my[D + 2] = p11 * d1 + p12 * d2;
     }
     my[3] = p00; my[4] = 0.0; my[5] = p02;
     my[D + 3] = 0.0; my[D + 4] = p11; my[D + 5] = p12;
@@ -239,40 +256,53 @@ __global__ __launch_bounds__(256) void k_lin_obs(int64_t N, const int* __restric
       my[6] = s0 * xn; my[7] = 0.0; my[8] = s0; my[9] = 0.0;
       my[D + 6] = 0.0; my[D + 7] = s1 * yn; my[D + 8] = 0.0; my[D + 9] = s1;
     }
-#pragma unroll
-    for (int q = 0; q < 3; ++q) {
-      my[2 * D + q] = p00 * R[q] + p02 * R[6 + q];
-      my[2 * D + 3 + q] = p11 * R[3 + q] + p12 * R[6 + q];
-    }
-    my[2 * D + 6] = ft0;
-    my[2 * D + 7] = ft1;
+    // R[p][q] = delta_pq + a (r x e_q)[p] + b (r_p r_q - delta_pq |r|^2);  Jp = Pi R needs rows 0, 1, 2
+    const double R00 = 1.0 + b * (r0 * r0 - th2), R01 = -a * r2 + b * r0 * r1, R02 = a * r1 + b * r0 * r2;
+    const double R10 = a * r2 + b * r1 * r0, R11 = 1.0 + b * (r1 * r1 - th2), R12 = -a * r0 + b * r1 * r2;
+    const double R20 = -a * r1 + b * r2 * r0, R21 = a * r0 + b * r2 * r1, R22 = 1.0 + b * (r2 * r2 - th2);
+    jb[0] = p00 * R00 + p02 * R20; jb[1] = p00 * R01 + p02 * R21; jb[2] = p00 * R02 + p02 * R22;
+    jb[3] = p11 * R10 + p12 * R20; jb[4] = p11 * R11 + p12 * R21; jb[5] = p11 * R12 + p12 * R22;
+    jb[6] = ft0; jb[7] = ft1;
   }
   double tot = block_sum256(cost, s_red);   // contains the barrier that publishes s_rec
   if (tid == 0) part[blockIdx.x] = tot;
-  const int64_t nvalid = (N - k0) < 256 ? (N - k0) : 256;
-  const int total = (int)nvalid * REC;
-  double* outp = rec + (size_t)k0 * REC;
-  for (int i = tid; i < total; i += 256) {
-    const int t = i / REC, q = i - t * REC;
-    outp[i] = s_rec[t * LDR + q];
+  const int nvalid = (int)((N - k0) < 256 ? (N - k0) : 256);
+  {
+    double* outp = recA + (size_t)k0 * WA;
+    for (int i = tid; i < nvalid * WA; i += 256) {
+      const int t = i / WA, q = i - t * WA;
+      outp[i] = s_rec[t * LDA + q];
+    }
+  }
+  __syncthreads();
+  {
+    double* my = &s_rec[tid * LDB];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) my[q] = jb[q];
+  }
+  __syncthreads();
+  {
+    double* outp = recB + (size_t)k0 * WB;
+    for (int i = tid; i < nvalid * WB; i += 256) {
+      const int t = i >> 3, q = i & 7;
+      outp[i] = s_rec[t * LDB + q];
+    }
   }
 }
 
 // per point: C_j = sum Jp~^T Jp~ (packed xx,xy,xz,yy,yz,zz), g_pj = sum Jp~^T f~ ; block partials of
 // ||g_p||^2 and max|g_p|.
-template <int D>
 __global__ __launch_bounds__(256) void k_point_blocks(int P, const int* __restrict__ pt_ptr,
-                                                      const double* __restrict__ rec,
+                                                      const double* __restrict__ recB,
                                                       double* __restrict__ Cp, double* __restrict__ gp,
                                                       double* __restrict__ part) {
-  constexpr int REC = 2 * D + 8;
   __shared__ double s_red[4];
   const int j = blockIdx.x * 256 + threadIdx.x;
   double g2 = 0.0, gm = 0.0, cm = 0.0;
   if (j < P) {
     double c0 = 0, c1 = 0, c2 = 0, c3 = 0, c4 = 0, c5 = 0, g0 = 0, g1 = 0, g2v = 0;
     for (int k = pt_ptr[j]; k < pt_ptr[j + 1]; ++k) {
-      const double* r = rec + (size_t)k * REC + 2 * D;
+      const double* r = recB + (size_t)k * 8;
       const double a0 = r[0], a1 = r[1], a2 = r[2], b0 = r[3], b1 = r[4], b2 = r[5], f0 = r[6], f1 = r[7];
       c0 += a0 * a0 + b0 * b0; c1 += a0 * a1 + b0 * b1; c2 += a0 * a2 + b0 * b2;
       c3 += a1 * a1 + b1 * b1; c4 += a1 * a2 + b1 * b2; c5 += a2 * a2 + b2 * b2;
@@ -292,42 +322,56 @@ __global__ __launch_bounds__(256) void k_point_blocks(int P, const int* __restri
 }
 
 // per camera: B_c = sum Jc~^T Jc~ (DxD), g_c = sum Jc~^T f~ over the camera's observations.
-// One workgroup per camera; tiles of 64 observations are gathered into LDS, thread e owns B[a][b].
+// One workgroup per chunk of <= 256 observations of one camera: the chunk's Jc~ rows and f~ are gathered into
+// LDS, thread e of each 128-thread half owns B[a][b] (or g[a]) over half of the chunk; the halves and then the
+// chunks of a camera are added in fixed order (k_cam_blocks_final).
 template <int D>
-__global__ __launch_bounds__(256) void k_cam_blocks(const int* __restrict__ cam_ptr,
-                                                    const int* __restrict__ cam_obs,
-                                                    const double* __restrict__ rec,
-                                                    double* __restrict__ B, double* __restrict__ gc) {
-  constexpr int REC = 2 * D + 8, W = 2 * D + 2, LDW = W + 1;
-  __shared__ double s[64 * LDW];
-  const int c = blockIdx.x, tid = threadIdx.x;
-  const int beg = cam_ptr[c], end = cam_ptr[c + 1];
-  const int a = tid / D, b = tid % D;
+__global__ __launch_bounds__(256) void k_cam_blocks_chunks(const int* __restrict__ cch_beg, const int* __restrict__ cch_end,
+                                                           const int* __restrict__ cam_obs,
+                                                           const double* __restrict__ recA,
+                                                           const double* __restrict__ recB, double* __restrict__ part) {
+  constexpr int W = 2 * D + 2, LDW = W + 1, NE = D * D + D;
+  __shared__ double s[256 * LDW];
+  __shared__ double s_half[128];
+  const int ch = blockIdx.x, tid = threadIdx.x;
+  const int beg = cch_beg[ch], cnt = cch_end[ch] - beg;
+  for (int i = tid; i < cnt * W; i += 256) {
+    const int o = i / W, q = i - o * W;
+    const int k = cam_obs[beg + o];
+    s[o * LDW + q] = (q < 2 * D) ? recA[(size_t)k * (2 * D) + q] : recB[(size_t)k * 8 + 6 + (q - 2 * D)];
+  }
+  __syncthreads();
+  const int e = tid & 127, half = tid >> 7;
+  const int o0 = half * ((cnt + 1) / 2), o1 = half ? cnt : ((cnt + 1) / 2);
   double acc = 0.0;
-  for (int base = beg; base < end; base += 64) {
-    const int cnt = (end - base) < 64 ? (end - base) : 64;
-    __syncthreads();
-    for (int i = tid; i < cnt * W; i += 256) {
-      const int o = i / W, q = i - o * W;
-      const int k = cam_obs[base + o];
-      s[o * LDW + q] = rec[(size_t)k * REC + (q < 2 * D ? q : q + 6)];
+  if (e < D * D) {
+    const int a = e / D, b = e - a * D;
+    for (int o = o0; o < o1; ++o) {
+      const double* r = &s[o * LDW];
+      acc += r[a] * r[b] + r[D + a] * r[D + b];
     }
-    __syncthreads();
-    if (tid < D * D) {
-      for (int o = 0; o < cnt; ++o) {
-        const double* r = &s[o * LDW];
-        acc += r[a] * r[b] + r[D + a] * r[D + b];
-      }
-    } else if (tid < D * D + D) {
-      const int aa = tid - D * D;
-      for (int o = 0; o < cnt; ++o) {
-        const double* r = &s[o * LDW];
-        acc += r[aa] * r[2 * D] + r[D + aa] * r[2 * D + 1];
-      }
+  } else if (e < NE) {
+    const int aa = e - D * D;
+    for (int o = o0; o < o1; ++o) {
+      const double* r = &s[o * LDW];
+      acc += r[aa] * r[2 * D] + r[D + aa] * r[2 * D + 1];
     }
   }
-  if (tid < D * D) B[(size_t)c * D * D + tid] = acc;
-  else if (tid < D * D + D) gc[(size_t)c * D + (tid - D * D)] = acc;
+  if (half == 1) s_half[e] = acc;
+  __syncthreads();
+  if (half == 0 && e < NE) part[(size_t)ch * NE + e] = acc + s_half[e];
+}
+template <int D>
+__global__ void k_cam_blocks_final(int C, const int* __restrict__ cch_ptr, const double* __restrict__ part,
+                                   double* __restrict__ B, double* __restrict__ gc) {
+  constexpr int NE = D * D + D;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= C * NE) return;
+  const int c = i / NE, e = i - c * NE;
+  double t = 0.0;
+  for (int ch = cch_ptr[c]; ch < cch_ptr[c + 1]; ++ch) t += part[(size_t)ch * NE + e];
+  if (e < D * D) B[(size_t)c * D * D + e] = t;
+  else gc[(size_t)c * D + (e - D * D)] = t;
 }
 
 // Regulariser rows of sfm_reconstruction.py:489-499 (cam_dim 10): residual, Jacobian w.r.t.
@@ -447,26 +491,27 @@ __global__ void k_point_factor(int P, double alpha, const double* __restrict__ C
   e[(size_t)j * 3 + 2] = m20 * g0 + m21 * g1 + m22 * g2;
 }
 
-// G_k[m][a] = sum_r Jc~[r][a] * V[r][m],  V = Jp~ M^T (2x3).  One thread per output element: reads of
-// Jc~ and writes of G are both coalesced over a.
+// G_k[m][a] = sum_r Jc~[r][a] * V[r][m],  V = Jp~ M^T (2x3).  16 lanes per observation (a = lane & 15 < D),
+// each lane produces the three m entries of its column: Jc~ reads and G writes are contiguous over a, the
+// 12 doubles of Jp~ and M are the same address for the whole group (one request per group).
 template <int D>
-__global__ __launch_bounds__(256) void k_build_G(int64_t total, const int* __restrict__ pt_idx,
-                                                 const double* __restrict__ rec,
+__global__ __launch_bounds__(256) void k_build_G(int64_t N, const int* __restrict__ pt_idx,
+                                                 const double* __restrict__ recA, const double* __restrict__ recB,
                                                  const double* __restrict__ Linv, double* __restrict__ G) {
-  constexpr int REC = 2 * D + 8;
-  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (i >= total) return;
-  const int64_t k = i / (3 * D);
-  const int q = (int)(i - k * (3 * D));
-  const int m = q / D, a = q - m * D;
-  const double* r = rec + (size_t)k * REC;
+  const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t k = t >> 4;
+  const int a = (int)(t & 15);
+  if (k >= N || a >= D) return;
+  const double* r = recA + (size_t)k * (2 * D);
   const double* M = Linv + (size_t)pt_idx[k] * 6;
-  const double* jp = r + 2 * D;
-  double v0, v1;
-  if (m == 0) { v0 = jp[0] * M[0]; v1 = jp[3] * M[0]; }
-  else if (m == 1) { v0 = jp[0] * M[1] + jp[1] * M[2]; v1 = jp[3] * M[1] + jp[4] * M[2]; }
-  else { v0 = jp[0] * M[3] + jp[1] * M[4] + jp[2] * M[5]; v1 = jp[3] * M[3] + jp[4] * M[4] + jp[5] * M[5]; }
-  G[i] = r[a] * v0 + r[D + a] * v1;
+  const double* jp = recB + (size_t)k * 8;
+  const double j0 = jp[0], j1 = jp[1], j2 = jp[2], j3 = jp[3], j4 = jp[4], j5 = jp[5];
+  const double m00 = M[0], m10 = M[1], m11 = M[2], m20 = M[3], m21 = M[4], m22 = M[5];
+  const double c0 = r[a], c1 = r[D + a];
+  double* g = G + (size_t)k * (3 * D) + a;
+  g[0] = c0 * (j0 * m00) + c1 * (j3 * m00);
+  g[D] = c0 * (j0 * m10 + j1 * m11) + c1 * (j3 * m10 + j4 * m11);
+  g[2 * D] = c0 * (j0 * m20 + j1 * m21 + j2 * m22) + c1 * (j3 * m20 + j4 * m21 + j5 * m22);
 }
 
 // Reduced camera system  S[c][c2] = [c == c2] B_c - sum_{(k,k2) on a shared track} G_k G_k2^T  (c <= c2, mirrored).
@@ -698,19 +743,18 @@ __global__ __launch_bounds__(256) void k_axpy_step(int64_t n_c, int64_t n_total,
 template <int D>
 __global__ __launch_bounds__(256) void k_step_obs(int64_t N, const int* __restrict__ cam_idx,
                                                   const int* __restrict__ pt_idx,
-                                                  const double* __restrict__ rec,
+                                                  const double* __restrict__ recA, const double* __restrict__ recB,
                                                   const double* __restrict__ pc, const double* __restrict__ pp,
                                                   double scale, double* __restrict__ part) {
-  constexpr int REC = 2 * D + 8;
   __shared__ double s_red[4];
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;   // (obs, row)
   double j2 = 0.0, gt = 0.0;
   if (i < 2 * N) {
     const int64_t k = i >> 1;
     const int row = (int)(i & 1);
-    const double* r = rec + (size_t)k * REC;
-    const double* jc = r + row * D;
-    const double* jp = r + 2 * D + row * 3;
+    const double* jc = recA + (size_t)k * (2 * D) + row * D;
+    const double* rb = recB + (size_t)k * 8;
+    const double* jp = rb + row * 3;
     const double* c = pc + (size_t)cam_idx[k] * D;
     const double* q = pp + (size_t)pt_idx[k] * 3;
     double t = jp[0] * q[0] + jp[1] * q[1] + jp[2] * q[2];
@@ -718,7 +762,7 @@ __global__ __launch_bounds__(256) void k_step_obs(int64_t N, const int* __restri
     for (int a = 0; a < D; ++a) t += jc[a] * c[a];
     t *= scale;
     j2 = t * t;
-    gt = r[2 * D + 6 + row] * t;
+    gt = rb[6 + row] * t;
   }
   double a = block_sum256(j2, s_red);
   double b = block_sum256(gt, s_red);
@@ -739,12 +783,11 @@ __global__ __launch_bounds__(256) void k_cost_obs(int64_t N, const int* __restri
     const double* cp = campre + (size_t)cam_idx[k] * CAMPRE;
     const size_t j = (size_t)pt_idx[k] * 3;
     const double X0 = pts[j], X1 = pts[j + 1], X2 = pts[j + 2];
-    const double Y0 = cp[0] * X0 + cp[1] * X1 + cp[2] * X2 + cp[36];
-    const double Y1 = cp[3] * X0 + cp[4] * X1 + cp[5] * X2 + cp[37];
-    const double Y2 = cp[6] * X0 + cp[7] * X1 + cp[8] * X2 + cp[38];
+    double Y0, Y1, Y2;
+    cam_project(cp, X0, X1, X2, Y0, Y1, Y2);
     const double iz = 1.0 / Y2;
-    const double f0 = cp[39] * (Y0 * iz) + cp[41] - uv[2 * k];
-    const double f1 = cp[40] * (Y1 * iz) + cp[42] - uv[2 * k + 1];
+    const double f0 = cp[6] * (Y0 * iz) + cp[8] - uv[2 * k];
+    const double f1 = cp[7] * (Y1 * iz) + cp[9] - uv[2 * k + 1];
     cost = 0.5 * (huber_rho0(f0) + huber_rho0(f1));
     if (err_out) err_out[k] = sqrt(f0 * f0 + f1 * f1);
   }
@@ -877,7 +920,7 @@ __global__ void k_set_intrinsics(int C, double fx, double fy, double cx, double 
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= C) return;
   double* o = cp + (size_t)c * CAMPRE;
-  o[39] = fx; o[40] = fy; o[41] = cx; o[42] = cy;
+  o[6] = fx; o[7] = fy; o[8] = cx; o[9] = cy;
 }
 
 extern "C" int sfm_ba_reproj_errors(sfm_handle h, const sfm_ba_problem* p, const double* x, int shared_k,
@@ -909,13 +952,15 @@ extern "C" int sfm_ba_linearize(sfm_handle h, const sfm_ba_problem* p, const dou
                        p->cy0, WS(L, campre));
     sfm_prof_begin(h, SFM_PROF_LIN_OBS);
     hipLaunchKernelGGL(k_lin_obs<DD>, dim3((unsigned)L.nblk_obs), dim3(256), 0, h->stream, N, p->cam_idx,
-                       p->pt_idx, p->uv, pts, WS(L, campre), WS(L, rec), WS(L, part_obs));
+                       p->pt_idx, p->uv, pts, WS(L, campre), WS(L, recA), WS(L, recB), WS(L, part_obs));
     sfm_prof_end(h, SFM_PROF_LIN_OBS);
     sfm_prof_begin(h, SFM_PROF_LIN_REST);
-    hipLaunchKernelGGL(k_point_blocks<DD>, dim3((unsigned)L.nblk_pt), dim3(256), 0, h->stream, P, p->pt_ptr,
-                       WS(L, rec), WS(L, Cp), WS(L, gp), WS(L, part_pt));
-    hipLaunchKernelGGL(k_cam_blocks<DD>, dim3(C), dim3(256), 0, h->stream, p->cam_ptr, p->cam_obs, WS(L, rec),
-                       WS(L, B), WS(L, gc));
+    hipLaunchKernelGGL(k_point_blocks, dim3((unsigned)L.nblk_pt), dim3(256), 0, h->stream, P, p->pt_ptr,
+                       WS(L, recB), WS(L, Cp), WS(L, gp), WS(L, part_pt));
+    hipLaunchKernelGGL(k_cam_blocks_chunks<DD>, dim3((unsigned)p->n_cchunks), dim3(256), 0, h->stream, p->cch_beg,
+                       p->cch_end, p->cam_obs, WS(L, recA), WS(L, recB), WS(L, cbl_part));
+    hipLaunchKernelGGL(k_cam_blocks_final<DD>, dim3(cdiv((int64_t)C * (DD * DD + DD), 256)), dim3(256), 0, h->stream, C,
+                       p->cch_ptr, WS(L, cbl_part), WS(L, B), WS(L, gc));
   });
   int nreg = 0;
   if (D == 10 && p->apply_reg) {
@@ -951,9 +996,8 @@ extern "C" int sfm_ba_schur_build(sfm_handle h, const sfm_ba_problem* p, double 
   hipLaunchKernelGGL(k_point_factor, dim3(cdiv(P, 256)), dim3(256), 0, h->stream, P, alpha, WS(L, Cp), WS(L, gp),
                      WS(L, Linv), WS(L, e));
   DISPATCH_D(D, {
-    const int64_t tot = N * 3 * DD;
-    hipLaunchKernelGGL(k_build_G<DD>, dim3(cdiv(tot, 256)), dim3(256), 0, h->stream, tot, p->pt_idx, WS(L, rec),
-                       WS(L, Linv), WS(L, G));
+    hipLaunchKernelGGL(k_build_G<DD>, dim3(cdiv(N * 16, 256)), dim3(256), 0, h->stream, N, p->pt_idx, WS(L, recA),
+                       WS(L, recB), WS(L, Linv), WS(L, G));
     sfm_prof_end(h, SFM_PROF_BUILD_G);
     sfm_prof_begin(h, SFM_PROF_SCHUR);
     if (p->n_items > 0)
@@ -1037,7 +1081,7 @@ extern "C" int sfm_ba_step(sfm_handle h, const sfm_ba_problem* p, const double* 
   hipLaunchKernelGGL(k_axpy_step, dim3(nblk_x), dim3(256), 0, h->stream, (int64_t)n, ntot, x, WS(L, pc), WS(L, pp),
                      scale, x_new, part_x);
   DISPATCH_D(D, hipLaunchKernelGGL(k_step_obs<DD>, dim3(nblk_rows), dim3(256), 0, h->stream, N, p->cam_idx,
-                                   p->pt_idx, WS(L, rec), WS(L, pc), WS(L, pp), scale, WS(L, part_obs)));
+                                   p->pt_idx, WS(L, recA), WS(L, recB), WS(L, pc), WS(L, pp), scale, WS(L, part_obs)));
   rc = launch_cost(h, p, L, ws, x_new, WS(L, pc), scale, 1, nullptr); if (rc) return rc;
   const int nreg = (D == 10 && p->apply_reg) ? C : 0;
   hipLaunchKernelGGL(k_step_finalize, dim3(1), dim3(256), 0, h->stream, WS(L, part_obs), (int)L.nblk_obs,

@@ -175,7 +175,7 @@ def test_layout_and_argument_checks_without_gpu():
     lay = _lib.BALayout()
     assert lib.sfm_ba_get_layout(200, 100000, 1000000, 10, 22000, 4000, ctypes.byref(lay)) == 0
     n = 2000
-    assert lay.reduce_S_count == n * n + n and lay.reduce_q_count == n + 2 and lay.rec_stride == 28 * 8
+    assert lay.reduce_S_count == n * n + n and lay.reduce_q_count == n + 2 and lay.rec_stride == 20 * 8
     assert lay.reduce_lin_count == 2 * n + 2
     assert lay.total_bytes < 1 << 30
     assert lib.sfm_ba_get_layout(200, 100, 1000, 7, 10, 10, ctypes.byref(lay)) != 0       # cam_dim must be 6 or 10
