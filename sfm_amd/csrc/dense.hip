@@ -6,7 +6,8 @@
 //   wave_chol32    : 32x32 diagonal block in ONE wavefront (lane = row, columns split over the two
 //                    half-waves, finished column broadcast through LDS, 1/sqrt by v_rsq_f64 + two Newton
 //                    steps instead of sqrt + divide)
-//   wave_inv32     : its inverse, also in one wavefront (lane = column)
+//   wave_inv32_follow : its inverse on a SECOND wavefront of the same workgroup, one column behind the
+//                    factor (producer/consumer through LDS), so it adds almost nothing to the chain
 //   k_chol_panel   : rows below the block as a 32-deep MFMA product with L_jj^-1
 //   k_chol_update  : rank-32 update of the trailing lower tiles on v_mfma_f64_16x16x4_f64, panel rows
 //                    staged in LDS (row stride 34 doubles = conflict-free ds_read_b64); LOOK-AHEAD: the
@@ -55,15 +56,25 @@ void dense_ws_carve(double* base, int n, DenseWs* w) {
 }
 
 // ------------------------------------------------------------------------------------ Cholesky
+// Value of the half-wave `hj` broadcast to both half-waves (lane i and lane i + 32 get lane (i + 32 hj)'s v):
+// v_permlane32_swap of a register with itself leaves {lower half twice, upper half twice}.
+__device__ __forceinline__ double half_bcast(double v, int hj) {
+  const unsigned lo = (unsigned)__double2loint(v), hi = (unsigned)__double2hiint(v);
+  const auto rlo = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
+  const auto rhi = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+  return __hiloint2double((int)(hj ? rhi[1] : rhi[0]), (int)(hj ? rlo[1] : rlo[0]));
+}
+
 // In-wave factorisation of a 32x32 SPD block.  Lane l = (row i = l & 31, half h = l >> 5) holds the 16
 // entries M[i][2t + h] of its row in a[t]: the two half-waves split the columns, so a rank-1 update costs
-// <= 16 FMAs per lane.  The finished column is broadcast through LDS (same wavefront: LDS is in order).
-// Writes L (lower, zeros above) to sL[32][33] and the reciprocal diagonal to srd[32]; returns false on a
-// non-positive pivot.  scol: 128 doubles of LDS (2 x 32 column buffers + 64 dump slots: the half-wave
-// that does not own the column stores into the dump slots - an INDEX select; a pointer select or a
-// predicated store here made hipcc use 256 + 92 registers).
-__device__ __forceinline__ bool wave_chol32(double (&a)[16], int lane, double* __restrict__ sL,
-                                            double* __restrict__ srd, double* __restrict__ scol) {
+// <= 16 FMAs per lane.  The serial chain pivot -> 1/sqrt -> column -> next pivot stays in registers
+// (v_permlane32_swap shares L[i][j] between the half-waves, v_readlane fetches L[j+1][j] for the next
+// pivot's column); the other columns take their L[q][j] from the copy of the column published in LDS,
+// sC[j*32 + i] = L[i][j] (same wavefront: LDS is in order), off the chain.  s_ready <- j + 1 after each
+// column lets a SECOND wavefront build L^-1 one column behind (wave_inv32_follow).
+// Returns false on a non-positive pivot.
+__device__ __forceinline__ bool wave_chol32(double (&a)[16], int lane, double* __restrict__ sC,
+                                            double* __restrict__ srd, int* __restrict__ s_ready) {
   const int i = lane & 31, h = lane >> 5;
   bool bad = false;
 #pragma unroll
@@ -72,66 +83,88 @@ __device__ __forceinline__ bool wave_chol32(double (&a)[16], int lane, double* _
     double piv = readlane_d(a[tj], j + 32 * hj);
     if (!(piv > 0.0)) { bad = true; piv = 1.0; }
     const double rinv = rsqrt_nr(piv);
-    const double colv = a[tj] * rinv;
-    a[tj] = (h == hj) ? colv : a[tj];
-    double* cb = scol + (j & 1) * 32;
-    scol[(h == hj) ? ((j & 1) * 32 + i) : (64 + lane)] = colv;
+    const double li = half_bcast(a[tj] * rinv, hj);            // L[i][j] in both half-waves
+    a[tj] = (h == hj) ? li : a[tj];
+    double* cb = sC + j * 32;
+    cb[i] = li;                                                // both halves store the same value
     srd[j] = rinv;                                             // uniform value, every lane stores it
-    const double li = cb[i];                                   // L[i][j] for both halves
-    if (hj == 0) {                                             // column 2 tj + 1 lives in a[tj] of half 1
-      const double upd = li * cb[2 * tj + 1];
-      a[tj] = (h == 1) ? a[tj] - upd : a[tj];
+    // Flag = relaxed workgroup-scope atomic (a plain store is deleted / its load hoisted out of the spin loop
+    // by hipcc, a `volatile` one becomes flat_store sc0 sc1 with a full drain on the pivot chain).  The
+    // wavefront-scope fence only pins the compiler's order; the LDS unit executes a wave's operations in order.
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __hip_atomic_store(s_ready, j + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    if (j < 31) {                                              // next pivot's column first, from registers
+      const int q = j + 1, hq = q & 1, tq = q >> 1;
+      const double lq = readlane_d(li, q);                     // L[q][j]
+      a[tq] = (h == hq) ? a[tq] - li * lq : a[tq];
     }
+    if (hj == 0) {
+      // j = 2 tj: column j + 1 (half 1, a[tj]) was the fast path; both halves continue at t = tj + 1
 #pragma unroll
-    for (int t = tj + 1; t < 16; ++t) a[t] -= li * cb[2 * t + h];
-  }
+      for (int t = tj + 1; t < 16; ++t) a[t] -= li * cb[2 * t + h];
+    } else {
+      // j = 2 tj + 1: column j + 1 = 2 (tj + 1) (half 0) was the fast path; half 1 still owes column 2 tj + 3
+      if (tj + 1 < 16) {
+        const double upd = li * cb[2 * (tj + 1) + 1];
+        a[tj + 1] = (h == 1) ? a[tj + 1] - upd : a[tj + 1];
+      }
 #pragma unroll
-  for (int t = 0; t < 16; ++t) {
-    const int q = 2 * t + h;
-    sL[i * 33 + q] = (q <= i) ? a[t] : 0.0;
+      for (int t = tj + 2; t < 16; ++t) a[t] -= li * cb[2 * t + h];
+    }
   }
   return !bad;
 }
 
-// Inverse of the 32x32 lower-triangular factor just left in sL (reciprocal diagonal in srd): lane t (both
-// half-waves alike) forward-substitutes column t; L is read from LDS by broadcast.  Result to sLi[32][33].
-__device__ __forceinline__ void wave_inv32(const double* __restrict__ sL, const double* __restrict__ srd, int lane,
-                                           double* __restrict__ sLi) {
+// Inverse of the factor being produced by wave_chol32 in ANOTHER wavefront of the same workgroup: lane t
+// (both half-waves alike) forward-substitutes column t; row r only needs columns <= r of L, so this runs one
+// column behind the factorisation instead of after it.  The producer never waits for the consumer, so the
+// spin cannot deadlock.  Result: sLi[r*33 + t] = (L^-1)[r][t].
+__device__ __forceinline__ void wave_inv32_follow(const double* __restrict__ sC, const double* __restrict__ srd,
+                                                  int* __restrict__ s_ready, int lane, double* __restrict__ sLi) {
   const int t = lane & 31;
   double x[32];
 #pragma unroll
   for (int r = 0; r < 32; ++r) {
+    while (__hip_atomic_load(s_ready, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < r + 1) __builtin_amdgcn_s_sleep(1);
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     double s = (r == t) ? 1.0 : 0.0;
 #pragma unroll
-    for (int c = 0; c < r; ++c) s -= sL[r * 33 + c] * x[c];
+    for (int c = 0; c < r; ++c) s -= sC[c * 32 + r] * x[c];
     x[r] = (r >= t) ? s * srd[r] : 0.0;
     sLi[r * 33 + t] = x[r];
   }
 }
 
-// Factor the first diagonal block (rows/cols j0 .. j0+31) in place; L_jj and 1/diag also go to Ld / rd
-// for the panel kernel.  One wavefront.
-__global__ __launch_bounds__(64) void k_chol_diag(double* __restrict__ A, int n, int j0, double* __restrict__ Ld,
+// Factor the first diagonal block (rows/cols j0 .. j0+31) in place; L_jj^-1 goes to Ld for the panel kernel.
+// Two wavefronts: 0 factors, 1 inverts one column behind.
+__global__ __launch_bounds__(128) void k_chol_diag(double* __restrict__ A, int n, int j0, double* __restrict__ Ld,
                                                   double* __restrict__ rd, int* __restrict__ fail) {
-  __shared__ double sL[32 * 33], srd[32], scol[128], sLi[32 * 33];
-  const int lane = threadIdx.x, i = lane & 31, h = lane >> 5;
+  __shared__ double sC[1024], srd[32], sLi[32 * 33];
+  __shared__ int s_ready;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int nb = (n - j0) < 32 ? (n - j0) : 32;
-  double a[16];
+  if (tid == 0) s_ready = 0;
+  __syncthreads();
+  if (w == 0) {
+    const int i = lane & 31, h = lane >> 5;
+    double a[16];
 #pragma unroll
-  for (int t = 0; t < 16; ++t) {
-    const int q = 2 * t + h;
-    a[t] = (i < nb && q < nb && q <= i) ? A[(size_t)(j0 + i) * n + j0 + q] : ((q == i) ? 1.0 : 0.0);
+    for (int t = 0; t < 16; ++t) {
+      const int q = 2 * t + h;
+      a[t] = (i < nb && q < nb && q <= i) ? A[(size_t)(j0 + i) * n + j0 + q] : ((q == i) ? 1.0 : 0.0);
+    }
+    const bool ok = wave_chol32(a, lane, sC, srd, &s_ready);
+    if (!ok && lane == 0) *fail = 1;
+  } else {
+    wave_inv32_follow(sC, srd, &s_ready, lane, sLi);
   }
-  const bool ok = wave_chol32(a, lane, sL, srd, scol);
-  if (!ok && lane == 0) *fail = 1;
-  for (int e = lane; e < 32 * 32; e += 64) {
+  __syncthreads();
+  for (int e = tid; e < 32 * 32; e += 128) {
     const int r = e >> 5, c = e & 31;
-    const double v = sL[r * 33 + c];
-    if (r < nb && c <= r) A[(size_t)(j0 + r) * n + j0 + c] = v;
+    if (r < nb && c <= r) A[(size_t)(j0 + r) * n + j0 + c] = sC[c * 32 + r];
+    Ld[e] = sLi[r * 33 + c];                                   // Ld carries L_jj^-1
   }
-  wave_inv32(sL, srd, lane, sLi);
-  for (int e = lane; e < 32 * 32; e += 64) Ld[e] = sLi[(e >> 5) * 33 + (e & 31)];     // Ld carries L_jj^-1
-  if (lane < 32) rd[lane] = srd[lane];
+  if (tid < 32) rd[tid] = srd[tid];
 }
 
 // Rows below the diagonal block:  X = A_panel L_jj^-T  as a 32-deep product with the explicit inverse
@@ -184,9 +217,14 @@ __global__ __launch_bounds__(256) void k_chol_update(double* __restrict__ A, int
                                                      double* __restrict__ rd, int* __restrict__ fail) {
   constexpr int LDP = 34;
   __shared__ double sI[64 * LDP], sJ[64 * LDP];
-  __shared__ double sL[32 * 33], srd[32], scol[128];
-  const int ti = blockIdx.y, tj = blockIdx.x, tid = threadIdx.x;
-  if (tj > ti) return;
+  __shared__ double sBlk[32 * 33], srd[32];
+  __shared__ int s_ready;
+  // 1-D grid over the lower-triangular tiles only: block b -> (ti, tj), tj <= ti, b = ti (ti + 1) / 2 + tj
+  const int tid = threadIdx.x;
+  int ti = (int)((sqrtf(8.0f * (float)blockIdx.x + 1.0f) - 1.0f) * 0.5f);
+  while ((ti + 1) * (ti + 2) / 2 <= (int)blockIdx.x) ++ti;
+  while (ti * (ti + 1) / 2 > (int)blockIdx.x) --ti;
+  const int tj = (int)blockIdx.x - ti * (ti + 1) / 2;
   const int lane = tid & 63, w = tid >> 6;
   const int rem_r = nrows - j1, rem_c = n - j1;
   const int I0 = ti * 64, J0 = tj * 64;
@@ -230,31 +268,35 @@ __global__ __launch_bounds__(256) void k_chol_update(double* __restrict__ A, int
       const bool inside = gr < rem_r && gcol < rem_c && gcol <= gr;
       // the next diagonal block (top-left nbn x nbn of tile (0,0)) goes to LDS for the in-wave factorisation;
       // a short last block leaves the bordered right-hand-side row (lr >= nbn) on the normal path
-      if (crit && lr < nbn && lc < nbn) { if (lc <= lr) sL[lr * 33 + lc] = v; }
+      if (crit && lr < nbn && lc < nbn) { if (lc <= lr) sBlk[lr * 33 + lc] = v; }
       else if (inside) A[(size_t)(j1 + gr) * n + j1 + gcol] = v;
     }
   if (!crit) return;
+  if (tid == 0) s_ready = 0;
   __syncthreads();
-  if (w != 0) return;
-  {
+  if (w < 2) __builtin_amdgcn_s_setprio(3);     // the serial chain: ahead of the bulk tiles sharing these SIMDs
+  double* sC = sJ;            // the panel staging areas are free again: column-major L (1024 + 64 dump slots)
+  double* sLi = sI;           // and L^-1 [32][33]
+  if (w == 0) {
     const int i = lane & 31, h = lane >> 5;
     double a[16];
 #pragma unroll
     for (int t = 0; t < 16; ++t) {
       const int q = 2 * t + h;
-      a[t] = (q <= i) ? ((i < nbn && q < nbn) ? sL[i * 33 + q] : ((q == i) ? 1.0 : 0.0)) : 0.0;
+      a[t] = (q <= i) ? ((i < nbn && q < nbn) ? sBlk[i * 33 + q] : ((q == i) ? 1.0 : 0.0)) : 0.0;
     }
-    const bool ok = wave_chol32(a, lane, sL, srd, scol);
+    const bool ok = wave_chol32(a, lane, sC, srd, &s_ready);
     if (!ok && lane == 0) *fail = 1;
-    for (int e = lane; e < 32 * 32; e += 64) {
-      const int r = e >> 5, c = e & 31;
-      if (r < nbn && c <= r) A[(size_t)(j1 + r) * n + j1 + c] = sL[r * 33 + c];
-    }
-    double* sLi = sI;                                  // the panel staging area is free again
-    wave_inv32(sL, srd, lane, sLi);
-    for (int e = lane; e < 32 * 32; e += 64) Ld[e] = sLi[(e >> 5) * 33 + (e & 31)];     // Ld carries L^-1
-    if (lane < 32) rd[lane] = srd[lane];
+  } else if (w == 1) {
+    wave_inv32_follow(sC, srd, &s_ready, lane, sLi);
   }
+  __syncthreads();
+  for (int e = tid; e < 32 * 32; e += 256) {
+    const int r = e >> 5, c = e & 31;
+    if (r < nbn && c <= r) A[(size_t)(j1 + r) * n + j1 + c] = sC[c * 32 + r];
+    Ld[e] = sLi[r * 33 + c];                                   // Ld carries L^-1 of the next diagonal block
+  }
+  if (tid < 32) rd[tid] = srd[tid];
 }
 
 // ------------------------------------------------------------------------------------ diagonal-block inverses
@@ -392,7 +434,7 @@ __global__ __launch_bounds__(256) void k_trsv_step(const double* __restrict__ L,
 
 // ------------------------------------------------------------------------------------ host
 int dense_cholesky(sfm_ctx* h, double* A, int n, int nrows, const DenseWs& w) {
-  hipLaunchKernelGGL(k_chol_diag, dim3(1), dim3(64), 0, h->stream, A, n, 0, w.Ld, w.rd, w.flag);
+  hipLaunchKernelGGL(k_chol_diag, dim3(1), dim3(128), 0, h->stream, A, n, 0, w.Ld, w.rd, w.flag);
   for (int j0 = 0; j0 < n; j0 += 32) {
     const int nb = (n - j0) < 32 ? (n - j0) : 32;
     const int j1 = j0 + nb;
@@ -401,7 +443,7 @@ int dense_cholesky(sfm_ctx* h, double* A, int n, int nrows, const DenseWs& w) {
     hipLaunchKernelGGL(k_chol_panel, dim3(cdiv(below, 64)), dim3(256), 0, h->stream, A, n, nrows, j0, w.panel, w.Ld);
     if (j1 < n) {         // trailing columns exist: update them and factor the next diagonal block
       const unsigned T = cdiv(below, 64);
-      hipLaunchKernelGGL(k_chol_update, dim3(T, T), dim3(256), 0, h->stream, A, n, nrows, j1, w.panel, w.Ld, w.rd, w.flag);
+      hipLaunchKernelGGL(k_chol_update, dim3(T * (T + 1) / 2), dim3(256), 0, h->stream, A, n, nrows, j1, w.panel, w.Ld, w.rd, w.flag);
     }
   }
   // inverses of the 128x128 diagonal blocks of L for the triangular solves
