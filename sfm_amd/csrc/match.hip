@@ -13,6 +13,7 @@
 // i.e. v_lshl_add_u32 + v_min_i32 + v_med3_i32 per candidate; keys are unpacked every 128 train rows.
 // Ties go to the lower train index (OpenCV's documented order); sqrtf is applied once at the end.
 #include "common.h"
+#include <cstdlib>
 
 typedef int v4i __attribute__((ext_vector_type(4)));
 typedef int v16i __attribute__((ext_vector_type(16)));
@@ -134,9 +135,11 @@ __global__ __launch_bounds__(256) void k_knn2_u8(const uint8_t* __restrict__ q, 
   for (int ch = 0; ch < n_chunks; ++ch) {
     const int buf = ch & 1;
     if (ch + 1 < n_chunks) load_chunk(ch + 1);
-    int m1[QB], m2[QB];
+    // two independent (best, second) key pairs per query block - even / odd accumulator registers - halve the
+    // serial min/med3 dependency chain; they are merged when the chunk is flushed
+    int m1[QB][2], m2[QB][2];
 #pragma unroll
-    for (int qb = 0; qb < QB; ++qb) { m1[qb] = 0x7FFFFFFF; m2[qb] = 0x7FFFFFFF; }
+    for (int qb = 0; qb < QB; ++qb) { m1[qb][0] = m1[qb][1] = 0x7FFFFFFF; m2[qb][0] = m2[qb][1] = 0x7FFFFFFF; }
 #pragma unroll 2
     for (int tile = 0; tile < CHUNK / 32; ++tile) {
       const int row = tile * 32 + l31;
@@ -164,9 +167,9 @@ __global__ __launch_bounds__(256) void k_knn2_u8(const uint8_t* __restrict__ q, 
         for (int r = 0; r < 16; ++r) {
           const int key = (acc[r] << 9) + k0[r];
           int nm2;
-          asm("v_med3_i32 %0, %1, %2, %3" : "=v"(nm2) : "v"(m1[qb]), "v"(m2[qb]), "v"(key));
-          m2[qb] = nm2;
-          m1[qb] = min(m1[qb], key);
+          asm("v_med3_i32 %0, %1, %2, %3" : "=v"(nm2) : "v"(m1[qb][r & 1]), "v"(m2[qb][r & 1]), "v"(key));
+          m2[qb][r & 1] = nm2;
+          m1[qb][r & 1] = min(m1[qb][r & 1], key);
         }
       }
     }
@@ -175,9 +178,12 @@ __global__ __launch_bounds__(256) void k_knn2_u8(const uint8_t* __restrict__ q, 
     const int cbase = (int)(t_beg + (int64_t)ch * CHUNK);
 #pragma unroll
     for (int qb = 0; qb < QB; ++qb) {
+      // keys carry the row index, so they are totally ordered: best two of the four
+      const int lo = min(m1[qb][0], m1[qb][1]), hi = max(m1[qb][0], m1[qb][1]);
+      const int second = min(hi, min(m2[qb][0], m2[qb][1]));
 #pragma unroll
       for (int s = 0; s < 2; ++s) {
-        const int m = s == 0 ? m1[qb] : m2[qb];
+        const int m = s == 0 ? lo : second;
         if ((m | 0xFF) == (KEY_SENTINEL | 0xFF) || m == 0x7FFFFFFF) continue;
         const int d2 = (m >> 8) + qnv[qb];
         const int idx = cbase + (m & 0xFF);
@@ -363,14 +369,18 @@ extern "C" int sfm_match_knn2(sfm_handle h, int metric, const void* q, int64_t n
     if (dim != 32 && dim != 64 && dim != 128)
       return sfm_fail(h, SFM_ERR_ARG, "sfm_match_knn2", "L2_U8 needs dim 32, 64 or 128");
     constexpr int QB = 2;
+    const char* qb_env = getenv("SFM_MATCH_QB");           // tuning knob (dim 128 only): 4 query blocks per wave
+    const bool qb4 = (dim == 128) && qb_env && qb_env[0] == '4';
     nsplit = pick_nsplit(nq, nt, 4 * QB * 32);
     const int64_t rps = align_up((nt + nsplit - 1) / nsplit, 128);
     nsplit = (int)((nt + rps - 1) / rps);
     hipLaunchKernelGGL(k_row_norm_u8, dim3(cdiv(nt, 256)), dim3(256), 0, h->stream, (const uint8_t*)t, nt, dim, 0x80, dim, tn);
     hipLaunchKernelGGL(k_row_norm_u8, dim3(cdiv(nq, 256)), dim3(256), 0, h->stream, (const uint8_t*)q, nq, dim, 0x7F, 0, qn);
-    const unsigned grid = cdiv(nq, 4 * QB * 32) * nsplit;
+    const unsigned grid = cdiv(nq, 4 * (qb4 ? 4 : QB) * 32) * nsplit;
     sfm_prof_begin(h, SFM_PROF_KNN);
-    if (dim == 128)
+    if (qb4)
+      hipLaunchKernelGGL((k_knn2_u8<4, 4>), dim3(grid), dim3(256), 0, h->stream, (const uint8_t*)q, nq, (const uint8_t*)t, nt, tn, qn, nsplit, rps, part);
+    else if (dim == 128)
       hipLaunchKernelGGL((k_knn2_u8<4, QB>), dim3(grid), dim3(256), 0, h->stream, (const uint8_t*)q, nq, (const uint8_t*)t, nt, tn, qn, nsplit, rps, part);
     else if (dim == 64)
       hipLaunchKernelGGL((k_knn2_u8<2, QB>), dim3(grid), dim3(256), 0, h->stream, (const uint8_t*)q, nq, (const uint8_t*)t, nt, tn, qn, nsplit, rps, part);

@@ -14,8 +14,11 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
-def golden_files(pattern="ba_"):
-    return sorted(f for f in os.listdir(GOLDEN) if f.startswith(pattern) and f.endswith(".npz"))
+def golden_files(pattern="ba_", include_large=True):
+    """Reference-generated BA goldens.  ba_bunny_* (35 cams / 2,555 pts: the reconstruction the reference ships)
+    is too large for the dense NumPy oracle (8015 x 8015) and is checked with the C oracle and on the GPU."""
+    out = sorted(f for f in os.listdir(GOLDEN) if f.startswith(pattern) and f.endswith(".npz"))
+    return [f for f in out if include_large or "bunny" not in f]
 
 
 def load_golden_problem(name):

@@ -13,7 +13,7 @@ from conftest import GOLDEN, ROOT, golden_files, load_golden_problem
 
 
 # ------------------------------------------------------------------ oracle pinned by the reference's own runs
-@pytest.mark.parametrize("name", golden_files())
+@pytest.mark.parametrize("name", golden_files(include_large=False))
 def test_oracle_reproduces_reference_run(name):
     from oracle import ba_oracle as bo
     g, prob, x0 = load_golden_problem(name)
