@@ -41,6 +41,7 @@ def parse():
     ap.add_argument("--match-reps", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-matcher", action="store_true")
+    ap.add_argument("--no-d6", action="store_true")
     return ap.parse_args()
 
 
@@ -149,6 +150,27 @@ def main():
     kernels = {k: {"ms_total": round(v[0], 3), "launches": v[1],
                    "share": round(v[0] / (elapsed * 1e3), 4)} for k, v in prof.items() if v[1] > 0}
 
+    # ------------------------------------------------------------------ secondary: the north_star's 2x(6+3) shape
+    ba_d6 = None
+    if d == 10 and not args.no_d6:
+        be.h.set_profiling(False)
+        be6 = GpuBA(sc.cams0[:, :6], pts0, ci, pi, uv, synth.K_REF, device=local_rank, comm=comm, structure=be.st)
+        st6 = TRFState(be6, max_nfev=10 ** 9, check_tolerances=False)
+        for _ in range(args.warmup):
+            st6.outer()
+        s0 = st6.n_solves
+        barrier_sync()
+        t6 = time.perf_counter()
+        for _ in range(args.steps):
+            st6.outer()
+        barrier_sync()
+        e6 = max_over_ranks(time.perf_counter() - t6)
+        ba_d6 = {"value": args.steps / e6, "unit": "LM-iterations/s", "ms_per_step": e6 / args.steps * 1e3,
+                 "damped_solves": st6.n_solves - s0, "cost_end": st6.cost,
+                 "workload": "same scene, camera block [rvec,t] with fixed K (cam_dim 6, n = %d)" % (6 * C)}
+        del be6, st6
+        torch.cuda.empty_cache()
+
     # ------------------------------------------------------------------ matcher workload (cfg2)
     matcher = None
     if not args.no_matcher:
@@ -210,7 +232,7 @@ def main():
                        "seed": 1004},
             "ba": {"damped_solves": n_solves, "trial_steps": n_trials, "cost_start": cost0, "cost_end": st.cost,
                    "solves_per_s": n_solves / elapsed, "kernels": kernels},
-            "roofline": roofline, "cpu_baseline": cpu_baseline, "matcher": matcher,
+            "ba_cam_dim6": ba_d6, "roofline": roofline, "cpu_baseline": cpu_baseline, "matcher": matcher,
         }
         print(json.dumps(out), flush=True)
     if use_dist:

@@ -24,7 +24,11 @@ def build(force=False, verbose=True):
         return LIB
     os.makedirs(os.path.dirname(LIB), exist_ok=True)
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    # -amdgpu-mfma-vgpr-form: MFMA results land in VGPRs (gfx950 has one unified register file); with the default
+    # AGPR form every accumulator value costs a v_accvgpr_read before the VALU can use it - in the matcher that
+    # was a quarter of all VALU work (profiles/r01_pmc_matcher.txt)
     cmd = [hipcc, "-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-shared",
+           "-mllvm", "-amdgpu-mfma-vgpr-form",
            "-I" + os.path.join(ROOT, "include"), "-o", LIB] + SRC
     if verbose:
         print(" ".join(cmd), flush=True)

@@ -114,7 +114,9 @@ __global__ __launch_bounds__(256) void k_knn2_u8(const uint8_t* __restrict__ q, 
     }
     if (tid < CHUNK) {
       const int64_t tr = base + tid;
-      stage_k0 = (tr < t_end) ? ((tn[tr] << 8) | tid) : (KEY_SENTINEL | tid);
+      // low 8 bits: row inside the 256-row window (two LDS chunks) the keys are unpacked after
+      const int wrow = ((ch & 1) << 7) | tid;
+      stage_k0 = (tr < t_end) ? ((tn[tr] << 8) | wrow) : (KEY_SENTINEL | wrow);
     }
   };
   auto store_chunk = [&](int buf) {
@@ -130,16 +132,18 @@ __global__ __launch_bounds__(256) void k_knn2_u8(const uint8_t* __restrict__ q, 
     if (tid < CHUNK) s_k0[buf][tid] = stage_k0;
   };
 
+  // two independent (best, second) key pairs per query block - even / odd accumulator registers - halve the
+  // serial min/med3 dependency chain; they are merged when the 256-row window is flushed
+  int m1[QB][2], m2[QB][2];
   if (n_chunks > 0) { load_chunk(0); store_chunk(0); }
   __syncthreads();
   for (int ch = 0; ch < n_chunks; ++ch) {
     const int buf = ch & 1;
     if (ch + 1 < n_chunks) load_chunk(ch + 1);
-    // two independent (best, second) key pairs per query block - even / odd accumulator registers - halve the
-    // serial min/med3 dependency chain; they are merged when the chunk is flushed
-    int m1[QB][2], m2[QB][2];
+    if ((ch & 1) == 0) {
 #pragma unroll
-    for (int qb = 0; qb < QB; ++qb) { m1[qb][0] = m1[qb][1] = 0x7FFFFFFF; m2[qb][0] = m2[qb][1] = 0x7FFFFFFF; }
+      for (int qb = 0; qb < QB; ++qb) { m1[qb][0] = m1[qb][1] = 0x7FFFFFFF; m2[qb][0] = m2[qb][1] = 0x7FFFFFFF; }
+    }
 #pragma unroll 2
     for (int tile = 0; tile < CHUNK / 32; ++tile) {
       const int row = tile * 32 + l31;
@@ -173,9 +177,10 @@ __global__ __launch_bounds__(256) void k_knn2_u8(const uint8_t* __restrict__ q, 
         }
       }
     }
-    // unpack this chunk's best two and merge into the running pair (later chunks = higher indices,
-    // so strict '<' keeps the lower index on equal d^2)
-    const int cbase = (int)(t_beg + (int64_t)ch * CHUNK);
+    // every second chunk (and at the end): unpack the window's best two and merge into the running pair
+    // (later windows = higher indices, so strict '<' keeps the lower index on equal d^2)
+    const int cbase = (int)(t_beg + (int64_t)(ch & ~1) * CHUNK);
+    if ((ch & 1) == 1 || ch + 1 == n_chunks) {
 #pragma unroll
     for (int qb = 0; qb < QB; ++qb) {
       // keys carry the row index, so they are totally ordered: best two of the four
@@ -190,6 +195,7 @@ __global__ __launch_bounds__(256) void k_knn2_u8(const uint8_t* __restrict__ q, 
         if (d2 < g1k[qb]) { g2k[qb] = g1k[qb]; g2i[qb] = g1i[qb]; g1k[qb] = d2; g1i[qb] = idx; }
         else if (d2 < g2k[qb]) { g2k[qb] = d2; g2i[qb] = idx; }
       }
+    }
     }
     if (ch + 1 < n_chunks) store_chunk(buf ^ 1);
     __syncthreads();

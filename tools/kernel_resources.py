@@ -3,7 +3,7 @@
 -Rpass-analysis=kernel-resource-usage remarks.  usage: tools/kernel_resources.py file.hip"""
 import re, subprocess, sys
 src = sys.argv[1]
-out = subprocess.run(["hipcc", "-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-Iinclude", "-c", src,
+out = subprocess.run(["hipcc", "-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-Iinclude", "-mllvm", "-amdgpu-mfma-vgpr-form", "-c", src,
                       "-o", "/dev/null", "-Rpass-analysis=kernel-resource-usage"], capture_output=True, text=True).stderr
 cur = None; rows = {}
 for line in out.splitlines():
