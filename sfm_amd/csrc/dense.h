@@ -3,8 +3,8 @@
 #include "common.h"
 
 struct DenseWs {
-  double* panel;   // [(n+1)][32] current panel
-  double* Ld;      // [32][32] factored diagonal block of the current step
+  double* panel;   // [(n+1)][64] current panel
+  double* Ld;      // [64][64] inverse of the diagonal block of the current step
   double* rd;      // unused spare
   double* Dinv;    // [ceil(n/128)][128][128] inverses of the diagonal blocks of L, row-major
   double* DinvT;   // same, transposed

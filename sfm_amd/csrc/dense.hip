@@ -40,13 +40,13 @@ __device__ __forceinline__ double wave_sum_d(double v) {
 
 int64_t dense_ws_doubles(int n) {
   const int64_t nb = (n + 127) / 128;
-  return align_up((int64_t)(n + 1) * 32, 32) + 32 * 32 + 32 + 2 * nb * 128 * 128 + nb * 2 * 64 * 64 + nb * 64 * 64 + 32;
+  return align_up((int64_t)(n + 1) * 64, 32) + 64 * 64 + 32 + 2 * nb * 128 * 128 + nb * 2 * 64 * 64 + nb * 64 * 64 + 32;
 }
 void dense_ws_carve(double* base, int n, DenseWs* w) {
   const int64_t nb = (n + 127) / 128;
   double* p = base;
-  w->panel = p; p += align_up((int64_t)(n + 1) * 32, 32);
-  w->Ld = p; p += 32 * 32;
+  w->panel = p; p += align_up((int64_t)(n + 1) * 64, 32);
+  w->Ld = p; p += 64 * 64;
   w->rd = p; p += 32;
   w->Dinv = p; p += nb * 128 * 128;
   w->DinvT = p; p += nb * 128 * 128;
@@ -120,7 +120,7 @@ __device__ __forceinline__ bool wave_chol32(double (&a)[16], int lane, double* _
 // column behind the factorisation instead of after it.  The producer never waits for the consumer, so the
 // spin cannot deadlock.  Result: sLi[r*33 + t] = (L^-1)[r][t].
 __device__ __forceinline__ void wave_inv32_follow(const double* __restrict__ sC, const double* __restrict__ srd,
-                                                  int* __restrict__ s_ready, int lane, double* __restrict__ sLi) {
+                                                  int* __restrict__ s_ready, int lane, double* __restrict__ sLi, int ldl) {
   const int t = lane & 31;
   double x[32];
 #pragma unroll
@@ -131,53 +131,149 @@ __device__ __forceinline__ void wave_inv32_follow(const double* __restrict__ sC,
 #pragma unroll
     for (int c = 0; c < r; ++c) s -= sC[c * 32 + r] * x[c];
     x[r] = (r >= t) ? s * srd[r] : 0.0;
-    sLi[r * 33 + t] = x[r];
+    sLi[r * ldl + t] = x[r];
   }
 }
 
-// Factor the first diagonal block (rows/cols j0 .. j0+31) in place; L_jj^-1 goes to Ld for the panel kernel.
-// Two wavefronts: 0 factors, 1 inverts one column behind.
-__global__ __launch_bounds__(128) void k_chol_diag(double* __restrict__ A, int n, int j0, double* __restrict__ Ld,
-                                                  double* __restrict__ rd, int* __restrict__ fail) {
-  __shared__ double sC[1024], srd[32], sLi[32 * 33];
-  __shared__ int s_ready;
-  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-  const int nb = (n - j0) < 32 ? (n - j0) : 32;
-  if (tid == 0) s_ready = 0;
+// ---- two-level factorisation + inversion of a 64x64 SPD tile held in LDS (all 256 threads of a workgroup)
+// sM [64][LDM] row-major, lower part valid (identity outside the valid nb x nb corner).  On return
+//   L  = [L11 0; L21 L22]:  L11 column-major in ... written to A by the caller-provided store lambda
+// The tile is processed as 2x2 blocks of 32: wavefront 0 runs the serial in-wave factor (wave_chol32),
+// wavefront 1 builds the inverse one column behind (wave_inv32_follow), all four waves do the 32^3 products
+// on v_mfma_f64_16x16x4_f64 (one 16x16 tile each).  LDS carve (doubles), given base pointer `w`:
+//   sM 64*66 | sC 1024 | sLi11 32*34 | sLi22 32*34 | sT 32*34 | srd 64 | flag (2 ints)
+constexpr int LDM = 66, LDL = 34;
+constexpr int CRIT64_DOUBLES = 64 * LDM + 1024 + 3 * 32 * LDL + 64 + 2;   // 8578 doubles; the update kernel stages 2 * 64 * LDM = 8448 in the same array
+static_assert(CRIT64_DOUBLES + 6 >= 2 * 64 * LDM, "staging must fit the shared array");
+
+struct Crit64 {
+  double *sM, *sC, *sLi11, *sLi22, *sT, *srd;
+  int* flag;
+};
+__device__ __forceinline__ Crit64 crit64_carve(double* base) {
+  Crit64 c;
+  c.sM = base; base += 64 * LDM;
+  c.sC = base; base += 1024;
+  c.sLi11 = base; base += 32 * LDL;
+  c.sLi22 = base; base += 32 * LDL;
+  c.sT = base; base += 32 * LDL;
+  c.srd = base; base += 64;
+  c.flag = (int*)base;
+  return c;
+}
+
+// one 16x16 output tile (tr, tc) of a 32x32x32 product; operands in LDS.
+//   A(r, k) = pa[r * lda + k];   B(k, c) = TRANSB ? pb[c * ldb + k] : pb[k * ldb + c]
+template <bool TRANSB>
+__device__ __forceinline__ v4d mm32_tile(const double* __restrict__ pa, int lda, const double* __restrict__ pb, int ldb,
+                                         int tr, int tc, int lane) {
+  const int r16 = lane & 15, kq = lane >> 4;
+  v4d acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+  for (int k0 = 0; k0 < 32; k0 += 4) {
+    const double a = pa[(tr * 16 + r16) * lda + k0 + kq];
+    const double b = TRANSB ? pb[(tc * 16 + r16) * ldb + k0 + kq] : pb[(k0 + kq) * ldb + tc * 16 + r16];
+    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
+  }
+  return acc;
+}
+
+// Factor + invert the tile in c.sM.  store_L(r, c, v) / store_Li(r, c, v) receive every lower-triangular
+// entry of L and L^-1 (64x64 coordinates); *ok is cleared on a non-positive pivot.  nb = valid size.
+template <class FL, class FI>
+__device__ __forceinline__ void crit64_run(const Crit64& c, int tid, FL store_L, FI store_Li, int* __restrict__ fail) {
+  const int lane = tid & 63, w = tid >> 6;
+  const int i = lane & 31, h = lane >> 5;
+  const int tr = w >> 1, tc = w & 1;
+  const int kq = lane >> 4, r16 = lane & 15;
+  if (tid == 0) { c.flag[0] = 0; c.flag[1] = 0; }
   __syncthreads();
+  if (w < 2) __builtin_amdgcn_s_setprio(3);     // the serial chain: ahead of the bulk tiles sharing these SIMDs
+  // ---- P1: A11 = L11 L11^T (wave 0), Li11 = L11^-1 (wave 1, one column behind)
   if (w == 0) {
-    const int i = lane & 31, h = lane >> 5;
     double a[16];
 #pragma unroll
-    for (int t = 0; t < 16; ++t) {
-      const int q = 2 * t + h;
-      a[t] = (i < nb && q < nb && q <= i) ? A[(size_t)(j0 + i) * n + j0 + q] : ((q == i) ? 1.0 : 0.0);
-    }
-    const bool ok = wave_chol32(a, lane, sC, srd, &s_ready);
-    if (!ok && lane == 0) *fail = 1;
-  } else {
-    wave_inv32_follow(sC, srd, &s_ready, lane, sLi);
+    for (int t = 0; t < 16; ++t) { const int q = 2 * t + h; a[t] = (q <= i) ? c.sM[i * LDM + q] : 0.0; }
+    if (!wave_chol32(a, lane, c.sC, c.srd, &c.flag[0]) && lane == 0) *fail = 1;
+  } else if (w == 1) {
+    wave_inv32_follow(c.sC, c.srd, &c.flag[0], lane, c.sLi11, LDL);
   }
   __syncthreads();
-  for (int e = tid; e < 32 * 32; e += 128) {
-    const int r = e >> 5, c = e & 31;
-    if (r < nb && c <= r) A[(size_t)(j0 + r) * n + j0 + c] = sC[c * 32 + r];
-    Ld[e] = sLi[r * 33 + c];                                   // Ld carries L_jj^-1
+  // ---- P2: L21 = A21 Li11^T
+  {
+    const v4d acc = mm32_tile<true>(c.sM + 32 * LDM, LDM, c.sLi11, LDL, tr, tc, lane);
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < 4; ++q) c.sM[(32 + tr * 16 + kq + 4 * q) * LDM + tc * 16 + r16] = acc[q];
   }
-  if (tid < 32) rd[tid] = srd[tid];
+  __syncthreads();
+  // ---- P2b: T = L21 Li11 ;  P3: A22 -= L21 L21^T
+  {
+    const v4d t = mm32_tile<false>(c.sM + 32 * LDM, LDM, c.sLi11, LDL, tr, tc, lane);
+    const v4d u = mm32_tile<true>(c.sM + 32 * LDM, LDM, c.sM + 32 * LDM, LDM, tr, tc, lane);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int r = tr * 16 + kq + 4 * q, cc = tc * 16 + r16;
+      c.sT[r * LDL + cc] = t[q];
+      c.sM[(32 + r) * LDM + 32 + cc] -= u[q];
+    }
+  }
+  // L11 / Li11 leave LDS now: sC is reused by the second factor, sLi11 later receives Li21
+  for (int e = tid; e < 32 * 32; e += 256) {
+    const int r = e >> 5, cc = e & 31;
+    if (cc <= r) { store_L(r, cc, c.sC[cc * 32 + r]); store_Li(r, cc, c.sLi11[r * LDL + cc]); }
+  }
+  __syncthreads();
+  // ---- P4: A22 = L22 L22^T, Li22
+  if (w == 0) {
+    double a[16];
+#pragma unroll
+    for (int t = 0; t < 16; ++t) { const int q = 2 * t + h; a[t] = (q <= i) ? c.sM[(32 + i) * LDM + 32 + q] : 0.0; }
+    if (!wave_chol32(a, lane, c.sC, c.srd + 32, &c.flag[1]) && lane == 0) *fail = 1;
+  } else if (w == 1) {
+    wave_inv32_follow(c.sC, c.srd + 32, &c.flag[1], lane, c.sLi22, LDL);
+  }
+  __syncthreads();
+  // ---- P5: Li21 = -Li22 T
+  {
+    const v4d acc = mm32_tile<false>(c.sLi22, LDL, c.sT, LDL, tr, tc, lane);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) store_Li(32 + tr * 16 + kq + 4 * q, tc * 16 + r16, -acc[q]);
+  }
+  for (int e = tid; e < 32 * 32; e += 256) {
+    const int r = e >> 5, cc = e & 31;
+    store_L(32 + r, cc, c.sM[(32 + r) * LDM + cc]);                          // L21 (full block)
+    if (cc <= r) { store_L(32 + r, 32 + cc, c.sC[cc * 32 + r]); store_Li(32 + r, 32 + cc, c.sLi22[r * LDL + cc]); }
+  }
 }
 
-// Rows below the diagonal block:  X = A_panel L_jj^-T  as a 32-deep product with the explicit inverse
+// Factor the first 64x64 diagonal block in place; its inverse goes to Li (64x64 row-major, zeros above the
+// diagonal) for the panel kernel and to inv64 for the triangular solves.
+__global__ __launch_bounds__(256) void k_chol_diag(double* __restrict__ A, int n, double* __restrict__ Li,
+                                                   double* __restrict__ inv64, int* __restrict__ fail) {
+  __shared__ double smem[CRIT64_DOUBLES + 6];     // static: with `extern __shared__` hipcc needs 256 + 68 registers here
+  const Crit64 c = crit64_carve(smem);
+  const int tid = threadIdx.x;
+  const int nb = n < 64 ? n : 64;
+  for (int e = tid; e < 64 * 64; e += 256) {
+    const int r = e >> 6, cc = e & 63;
+    c.sM[r * LDM + cc] = (r < nb && cc < nb) ? ((cc <= r) ? A[(size_t)r * n + cc] : 0.0) : ((r == cc) ? 1.0 : 0.0);
+    Li[e] = 0.0;
+    inv64[e] = 0.0;
+  }
+  __syncthreads();
+  crit64_run(c, tid,
+             [&](int r, int cc, double v) { if (r < nb && cc < nb) A[(size_t)r * n + cc] = v; },
+             [&](int r, int cc, double v) { Li[r * 64 + cc] = v; inv64[r * 64 + cc] = v; }, fail);
+}
+
+// Rows below the diagonal block:  X = A_panel L_jj^-T  as a 64-deep product with the explicit inverse
 // Li = L_jj^-1 (from the look-ahead workgroup):  X[r][c] = sum_{k<=c} A[r][k] Li[c][k]  on
-// v_mfma_f64_16x16x4_f64, wave w = 16 rows, two 16-column tiles.  64 rows per workgroup.
+// v_mfma_f64_16x16x4_f64, wave w = 16 rows, four 16-column tiles.  64 rows per workgroup.
 __global__ __launch_bounds__(256) void k_chol_panel(double* __restrict__ A, int n, int nrows, int j0,
                                                     double* __restrict__ panel, const double* __restrict__ Li) {
-  constexpr int LDI = 34;
-  __shared__ double sLi[32 * LDI];
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-  const int nb = (n - j0) < 32 ? (n - j0) : 32;
-  for (int e = tid; e < 32 * 32; e += 256) sLi[(e >> 5) * LDI + (e & 31)] = Li[e];
-  __syncthreads();
+  const int nb = (n - j0) < 64 ? (n - j0) : 64;
   const int j1 = j0 + nb;
   const int r16 = lane & 15, kq = lane >> 4;
   const int rbase = j1 + blockIdx.x * 64 + w * 16;     // first global row of this wave
@@ -185,40 +281,44 @@ __global__ __launch_bounds__(256) void k_chol_panel(double* __restrict__ A, int 
   const int arow = rbase + r16;
   const bool aok = arow < nrows;
   const double* ap = A + (size_t)arow * n + j0;
-  v4d acc[2] = {(v4d){0.0, 0.0, 0.0, 0.0}, (v4d){0.0, 0.0, 0.0, 0.0}};
+  // the 16 A-operand values of this lane (k = 4 s + kq), issued together
+  double av[16];
 #pragma unroll
-  for (int k0 = 0; k0 < 32; k0 += 4) {
-    const double a = (aok && (k0 + kq) < nb) ? ap[k0 + kq] : 0.0;
+  for (int s4 = 0; s4 < 16; ++s4) av[s4] = (aok && (4 * s4 + kq) < nb) ? ap[4 * s4 + kq] : 0.0;
+  v4d acc[4];
 #pragma unroll
-    for (int t = 0; t < 2; ++t) {
-      const double b = sLi[(t * 16 + r16) * LDI + k0 + kq];
-      acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[t], 0, 0, 0);
-    }
+  for (int t = 0; t < 4; ++t) acc[t] = (v4d){0.0, 0.0, 0.0, 0.0};
+  // Li is lower triangular: column tile t (columns 16 t ..) only has k <= 16 t + 15; B operand read from L2
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    const double* bp = Li + (size_t)(t * 16 + r16) * 64 + kq;
+#pragma unroll
+    for (int s4 = 0; s4 < 4 * (t + 1); ++s4)
+      acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[s4], bp[4 * s4], acc[t], 0, 0, 0);
   }
 #pragma unroll
-  for (int t = 0; t < 2; ++t)
+  for (int t = 0; t < 4; ++t)
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int row = rbase + kq + 4 * i, col = t * 16 + r16;
       if (row < nrows) {
         const double v = (col < nb) ? acc[t][i] : 0.0;
         if (col < nb) A[(size_t)row * n + j0 + col] = v;
-        panel[(size_t)(row - j1) * 32 + col] = v;
+        panel[(size_t)(row - j1) * 64 + col] = v;
       }
     }
 }
 
-// Rank-32 update of the trailing lower 64x64 tiles on v_mfma_f64_16x16x4_f64 (panel rows staged in LDS,
-// row stride 34 doubles = conflict-free ds_read_b64).  Look-ahead: the workgroup of tile (0,0) then factors
-// the NEXT diagonal block (the top-left 32x32 of its tile) in wavefront 0 and publishes L / 1/diag for the
+// Rank-64 update of the trailing lower 64x64 tiles on v_mfma_f64_16x16x4_f64 (panel rows staged in LDS in two
+// 32-deep halves, row stride 34 doubles = conflict-free ds_read_b64).  Look-ahead: the workgroup of tile
+// (0,0) then factors AND inverts the next 64x64 diagonal block in LDS (crit64_run) and publishes L^-1 for the
 // next panel kernel, so the serial factorisation chain never waits for a kernel of its own.
 __global__ __launch_bounds__(256) void k_chol_update(double* __restrict__ A, int n, int nrows, int j1,
-                                                     const double* __restrict__ panel, double* __restrict__ Ld,
-                                                     double* __restrict__ rd, int* __restrict__ fail) {
-  constexpr int LDP = 34;
-  __shared__ double sI[64 * LDP], sJ[64 * LDP];
-  __shared__ double sBlk[32 * 33], srd[32];
-  __shared__ int s_ready;
+                                                     const double* __restrict__ panel, double* __restrict__ Li,
+                                                     double* __restrict__ inv64_next, int* __restrict__ fail) {
+  __shared__ double smem[CRIT64_DOUBLES + 6];     // 68.7 KB static (gfx950 allows up to 160 KB): 2 workgroups per CU
+  double* sI = smem;                 // [64][LDM]
+  double* sJ = smem + 64 * LDM;      // [64][LDM]   (the factor's buffers later reuse this space)
   // 1-D grid over the lower-triangular tiles only: block b -> (ti, tj), tj <= ti, b = ti (ti + 1) / 2 + tj
   const int tid = threadIdx.x;
   int ti = (int)((sqrtf(8.0f * (float)blockIdx.x + 1.0f) - 1.0f) * 0.5f);
@@ -228,11 +328,6 @@ __global__ __launch_bounds__(256) void k_chol_update(double* __restrict__ A, int
   const int lane = tid & 63, w = tid >> 6;
   const int rem_r = nrows - j1, rem_c = n - j1;
   const int I0 = ti * 64, J0 = tj * 64;
-  for (int i = tid; i < 64 * 32; i += 256) {
-    const int r = i >> 5, c = i & 31;
-    sI[r * LDP + c] = (I0 + r < rem_r) ? panel[(size_t)(I0 + r) * 32 + c] : 0.0;
-    sJ[r * LDP + c] = (J0 + r < rem_c) ? panel[(size_t)(J0 + r) * 32 + c] : 0.0;
-  }
   // prefetch the C tile this lane updates (rows 16 w + (lane>>4) + 4 i, cols 16 t + (lane&15))
   const int col16 = lane & 15, rq = lane >> 4;
   double cv[4][4];
@@ -243,21 +338,28 @@ __global__ __launch_bounds__(256) void k_chol_update(double* __restrict__ A, int
       const int gr = I0 + w * 16 + rq + 4 * i, gcol = J0 + t * 16 + col16;
       cv[t][i] = (gr < rem_r && gcol < rem_c && gcol <= gr) ? A[(size_t)(j1 + gr) * n + j1 + gcol] : 0.0;
     }
-  __syncthreads();
   v4d acc[4];
 #pragma unroll
   for (int t = 0; t < 4; ++t) acc[t] = (v4d){0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-  for (int k0 = 0; k0 < 32; k0 += 4) {
-    const double a = sI[(w * 16 + col16) * LDP + k0 + rq];
+  for (int i = tid; i < 64 * 64; i += 256) {
+    const int r = i >> 6, c = i & 63;
+    sI[r * LDM + c] = (I0 + r < rem_r) ? panel[(size_t)(I0 + r) * 64 + c] : 0.0;
+    sJ[r * LDM + c] = (J0 + r < rem_c) ? panel[(size_t)(J0 + r) * 64 + c] : 0.0;
+  }
+  __syncthreads();
+#pragma unroll 4
+  for (int k0 = 0; k0 < 64; k0 += 4) {
+    const double a = sI[(w * 16 + col16) * LDM + k0 + rq];
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
-      const double b = sJ[(t * 16 + col16) * LDP + k0 + rq];
+      const double b = sJ[(t * 16 + col16) * LDM + k0 + rq];
       acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[t], 0, 0, 0);
     }
   }
   const bool crit = (ti == 0 && tj == 0);
-  const int nbn = rem_c < 32 ? rem_c : 32;        // size of the next diagonal block (rem_c >= 1 here)
+  const int nbn = rem_c < 64 ? rem_c : 64;        // size of the next diagonal block (rem_c >= 1 here)
+  if (crit) __syncthreads();                       // staging is about to become the factor's tile buffer
+  const Crit64 c = crit64_carve(smem);
 #pragma unroll
   for (int t = 0; t < 4; ++t)
 #pragma unroll
@@ -266,37 +368,23 @@ __global__ __launch_bounds__(256) void k_chol_update(double* __restrict__ A, int
       const int gr = I0 + lr, gcol = J0 + lc;
       const double v = cv[t][i] - acc[t][i];
       const bool inside = gr < rem_r && gcol < rem_c && gcol <= gr;
-      // the next diagonal block (top-left nbn x nbn of tile (0,0)) goes to LDS for the in-wave factorisation;
-      // a short last block leaves the bordered right-hand-side row (lr >= nbn) on the normal path
-      if (crit && lr < nbn && lc < nbn) { if (lc <= lr) sBlk[lr * 33 + lc] = v; }
+      // the next diagonal block (top-left nbn x nbn of tile (0,0)) goes to LDS for the factorisation; a short
+      // last block leaves the bordered right-hand-side row (lr >= nbn) on the normal path
+      if (crit && lr < nbn && lc < nbn) { if (lc <= lr) c.sM[lr * LDM + lc] = v; }
       else if (inside) A[(size_t)(j1 + gr) * n + j1 + gcol] = v;
     }
   if (!crit) return;
-  if (tid == 0) s_ready = 0;
-  __syncthreads();
-  if (w < 2) __builtin_amdgcn_s_setprio(3);     // the serial chain: ahead of the bulk tiles sharing these SIMDs
-  double* sC = sJ;            // the panel staging areas are free again: column-major L (1024 + 64 dump slots)
-  double* sLi = sI;           // and L^-1 [32][33]
-  if (w == 0) {
-    const int i = lane & 31, h = lane >> 5;
-    double a[16];
-#pragma unroll
-    for (int t = 0; t < 16; ++t) {
-      const int q = 2 * t + h;
-      a[t] = (q <= i) ? ((i < nbn && q < nbn) ? sBlk[i * 33 + q] : ((q == i) ? 1.0 : 0.0)) : 0.0;
-    }
-    const bool ok = wave_chol32(a, lane, sC, srd, &s_ready);
-    if (!ok && lane == 0) *fail = 1;
-  } else if (w == 1) {
-    wave_inv32_follow(sC, srd, &s_ready, lane, sLi);
+  // identity outside the valid corner, zero the strict upper part the factor reads as "<= i" only
+  for (int e = tid; e < 64 * 64; e += 256) {
+    const int r = e >> 6, cc = e & 63;
+    if (r >= nbn || cc >= nbn) c.sM[r * LDM + cc] = (r == cc) ? 1.0 : 0.0;
+    Li[e] = 0.0;
+    inv64_next[e] = 0.0;
   }
   __syncthreads();
-  for (int e = tid; e < 32 * 32; e += 256) {
-    const int r = e >> 5, c = e & 31;
-    if (r < nbn && c <= r) A[(size_t)(j1 + r) * n + j1 + c] = sC[c * 32 + r];
-    Ld[e] = sLi[r * 33 + c];                                   // Ld carries L^-1 of the next diagonal block
-  }
-  if (tid < 32) rd[tid] = srd[tid];
+  crit64_run(c, tid,
+             [&](int r, int cc, double v) { if (r < nbn && cc < nbn) A[(size_t)(j1 + r) * n + j1 + cc] = v; },
+             [&](int r, int cc, double v) { Li[r * 64 + cc] = v; inv64_next[r * 64 + cc] = v; }, fail);
 }
 
 // ------------------------------------------------------------------------------------ diagonal-block inverses
@@ -320,6 +408,10 @@ __global__ __launch_bounds__(64) void k_inv64(const double* __restrict__ L, int 
     x[r] = (r >= t) ? s / sLd[r * 65 + r] : 0.0;
     out[r * 64 + t] = x[r];                      // coalesced over t
   }
+}
+
+__global__ void k_set_identity64(double* __restrict__ m) {
+  for (int e = threadIdx.x; e < 64 * 64; e += blockDim.x) m[e] = ((e >> 6) == (e & 63)) ? 1.0 : 0.0;
 }
 
 // 128-block = [A 0; B C]:  inverse = [Ai 0; -Ci B Ai, Ci].  One workgroup per block; both 64x64x64 products
@@ -434,21 +526,23 @@ __global__ __launch_bounds__(256) void k_trsv_step(const double* __restrict__ L,
 
 // ------------------------------------------------------------------------------------ host
 int dense_cholesky(sfm_ctx* h, double* A, int n, int nrows, const DenseWs& w) {
-  hipLaunchKernelGGL(k_chol_diag, dim3(1), dim3(128), 0, h->stream, A, n, 0, w.Ld, w.rd, w.flag);
-  for (int j0 = 0; j0 < n; j0 += 32) {
-    const int nb = (n - j0) < 32 ? (n - j0) : 32;
+  hipLaunchKernelGGL(k_chol_diag, dim3(1), dim3(256), 0, h->stream, A, n, w.Ld, w.inv64, w.flag);
+  for (int j0 = 0; j0 < n; j0 += 64) {
+    const int nb = (n - j0) < 64 ? (n - j0) : 64;
     const int j1 = j0 + nb;
     const int below = nrows - j1;
     if (below <= 0) break;
     hipLaunchKernelGGL(k_chol_panel, dim3(cdiv(below, 64)), dim3(256), 0, h->stream, A, n, nrows, j0, w.panel, w.Ld);
-    if (j1 < n) {         // trailing columns exist: update them and factor the next diagonal block
+    if (j1 < n) {         // trailing columns exist: update them; tile (0,0) factors + inverts the next diagonal block
       const unsigned T = cdiv(below, 64);
-      hipLaunchKernelGGL(k_chol_update, dim3(T * (T + 1) / 2), dim3(256), 0, h->stream, A, n, nrows, j1, w.panel, w.Ld, w.rd, w.flag);
+      hipLaunchKernelGGL(k_chol_update, dim3(T * (T + 1) / 2), dim3(256), 0, h->stream, A, n, nrows, j1, w.panel, w.Ld,
+                         w.inv64 + (size_t)(j1 / 64) * 64 * 64, w.flag);
     }
   }
-  // inverses of the 128x128 diagonal blocks of L for the triangular solves
+  // 128x128 diagonal-block inverses for the triangular solves from the 64x64 ones the factorisation left behind
   const unsigned nb128 = cdiv(n, 128);
-  hipLaunchKernelGGL(k_inv64, dim3(2 * nb128), dim3(64), 0, h->stream, A, n, w.inv64);
+  if ((cdiv(n, 64) & 1u) != 0)      // odd number of 64-blocks: the partner of the last one is an identity block
+    hipLaunchKernelGGL(k_set_identity64, dim3(1), dim3(256), 0, h->stream, w.inv64 + (size_t)cdiv(n, 64) * 64 * 64);
   hipLaunchKernelGGL(k_inv_merge, dim3(nb128), dim3(256), 0, h->stream, A, n, w.inv64, w.Dinv, w.DinvT);
   SFM_LAUNCH_CHECK(h, "dense_cholesky");
   return SFM_OK;
