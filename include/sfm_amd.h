@@ -108,6 +108,9 @@ typedef struct {
   const int32_t* item_beg;   /* [n_items] ranges into pair_k / pair_k2 */
   const int32_t* item_end;   /* [n_items] */
   int64_t n_items;
+  const int32_t* xcd_ptr;    /* [9]  item ids of block rows c = x (mod 8): xcd_items[xcd_ptr[x] .. xcd_ptr[x+1]) */
+  const int32_t* xcd_items;  /* [n_items] (workgroup b of the Schur kernel serves group b % 8: XCD-local L2 reuse of G) */
+  int64_t xcd_max_items;     /* largest of the 8 groups */
   const int32_t* cch_ptr;    /* [n_cams+1] chunks per camera: each <= 256 consecutive entries of cam_obs of ONE camera */
   const int32_t* cch_beg;    /* [n_cchunks] ranges into cam_obs */
   const int32_t* cch_end;    /* [n_cchunks] */

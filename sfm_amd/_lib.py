@@ -24,6 +24,7 @@ class BAProblem(C.Structure):
                 ("cam_obs", vp), ("blk_ptr", vp), ("pair_k", vp), ("pair_k2", vp),
                 ("n_pairs", i64),
                 ("item_ptr", vp), ("item_beg", vp), ("item_end", vp), ("n_items", i64),
+                ("xcd_ptr", vp), ("xcd_items", vp), ("xcd_max_items", i64),
                 ("cch_ptr", vp), ("cch_beg", vp), ("cch_end", vp), ("n_cchunks", i64),
                 ("fx0", f64), ("fy0", f64), ("cx0", f64), ("cy0", f64),
                 ("width", f64), ("height", f64), ("reg_weight", f64),

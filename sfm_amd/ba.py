@@ -46,6 +46,8 @@ class GpuBA:
         self.t_blk_ptr, self.t_pair_k, self.t_pair_k2 = up(st.blk_ptr), up(st.pair_k), up(st.pair_k2)
         self.t_item_ptr, self.t_item_beg, self.t_item_end = up(st.item_ptr), up(st.item_beg), up(st.item_end)
         self.t_cch_ptr, self.t_cch_beg, self.t_cch_end = up(st.cch_ptr), up(st.cch_beg), up(st.cch_end)
+        self.t_xcd_ptr, self.t_xcd_items = up(st.xcd_ptr), up(st.xcd_items)
+        self.xcd_max = int(np.max(np.diff(st.xcd_ptr)))
         lay = _lib.BALayout()
         rc = self.h.lib.sfm_ba_get_layout(self.C, self.P, self.N, self.d, st.n_items, st.n_cchunks, C.byref(lay))
         if rc != 0:
@@ -63,9 +65,11 @@ class GpuBA:
                         ("pt_ptr", self.t_pt_ptr), ("cam_ptr", self.t_cam_ptr), ("cam_obs", self.t_cam_obs),
                         ("blk_ptr", self.t_blk_ptr), ("pair_k", self.t_pair_k), ("pair_k2", self.t_pair_k2),
                         ("item_ptr", self.t_item_ptr), ("item_beg", self.t_item_beg), ("item_end", self.t_item_end),
-                        ("cch_ptr", self.t_cch_ptr), ("cch_beg", self.t_cch_beg), ("cch_end", self.t_cch_end)):
+                        ("cch_ptr", self.t_cch_ptr), ("cch_beg", self.t_cch_beg), ("cch_end", self.t_cch_end),
+                        ("xcd_ptr", self.t_xcd_ptr), ("xcd_items", self.t_xcd_items)):
             setattr(p, name, t.data_ptr())
         p.n_pairs, p.n_items, p.n_cchunks = st.n_pairs, st.n_items, st.n_cchunks
+        p.xcd_max_items = self.xcd_max
         p.fx0, p.fy0, p.cx0, p.cy0 = (float(v) for v in K0)
         p.width, p.height, p.reg_weight = float(width), float(height), float(reg_weight)
         p.workspace, p.workspace_bytes = self.ws.data_ptr(), lay.total_bytes

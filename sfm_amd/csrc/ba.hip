@@ -522,13 +522,19 @@ __global__ __launch_bounds__(256) void k_build_G(int64_t N, const int* __restric
 // 16 gathers of 8 pairs are in flight together.  k_schur_assemble then sums the items of each block in
 // order (bitwise reproducible), adds B_c on the diagonal and writes the block and its mirror.
 template <int D>
-__global__ __launch_bounds__(256) void k_schur_items(int n_items, const int* __restrict__ item_beg,
+__global__ __launch_bounds__(256) void k_schur_items(const int* __restrict__ xcd_ptr, const int* __restrict__ xcd_items,
+                                                     const int* __restrict__ item_beg,
                                                      const int* __restrict__ item_end,
                                                      const int* __restrict__ pair_k, const int* __restrict__ pair_k2,
                                                      const double* __restrict__ G, double* __restrict__ part) {
   const int lane = threadIdx.x & 63;
-  const int it = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (it >= n_items) return;
+  // workgroup b serves item group b % 8 (block rows c = b % 8 mod 8): with the round-robin XCD placement one
+  // XCD sees every item of a camera's block row, so that camera's G blocks (1.2 MB at 5,000 observations) are
+  // re-read from its 4 MB L2 instead of the fabric (speed only - any placement gives the same result)
+  const int grp = blockIdx.x & 7;
+  const int pos = xcd_ptr[grp] + (blockIdx.x >> 3) * 4 + (threadIdx.x >> 6);
+  if (pos >= xcd_ptr[grp + 1]) return;
+  const int it = xcd_items[pos];
   const int beg = item_beg[it], end = item_end[it];
   const int row = lane & 15, m = lane >> 4;
   const bool valid = (row < D) && (m < 3);
@@ -872,7 +878,7 @@ static int check_problem(sfm_ctx* h, const sfm_ba_problem* p, Lay* L) {
     return sfm_fail(h, SFM_ERR_ARG, "sfm_ba", "bad problem sizes / cam_dim");
   if (!p->cam_idx || !p->pt_idx || !p->uv || !p->pt_ptr || !p->cam_ptr || !p->cam_obs || !p->blk_ptr ||
       (p->n_pairs > 0 && (!p->pair_k || !p->pair_k2)) || !p->item_ptr || !p->item_beg || !p->item_end ||
-      !p->cch_ptr || !p->cch_beg || !p->cch_end || !p->workspace)
+      !p->cch_ptr || !p->cch_beg || !p->cch_end || !p->xcd_ptr || !p->xcd_items || p->xcd_max_items < 0 || !p->workspace)
     return sfm_fail(h, SFM_ERR_ARG, "sfm_ba", "null pointer in problem");
   if ((int64_t)p->n_cams * p->cam_dim > 32000) return sfm_fail(h, SFM_ERR_ARG, "sfm_ba", "reduced system too large");
   *L = ba_layout(p->n_cams, p->n_pts, p->n_obs, p->cam_dim, p->n_items, p->n_cchunks);
@@ -1000,9 +1006,9 @@ extern "C" int sfm_ba_schur_build(sfm_handle h, const sfm_ba_problem* p, double 
                        WS(L, recB), WS(L, Linv), WS(L, G));
     sfm_prof_end(h, SFM_PROF_BUILD_G);
     sfm_prof_begin(h, SFM_PROF_SCHUR);
-    if (p->n_items > 0)
-      hipLaunchKernelGGL(k_schur_items<DD>, dim3(cdiv(p->n_items, 4)), dim3(256), 0, h->stream, (int)p->n_items,
-                         p->item_beg, p->item_end, p->pair_k, p->pair_k2, WS(L, G), WS(L, sch_part));
+    if (p->n_items > 0)   // 8 groups x ceil(largest group / 4) workgroups
+      hipLaunchKernelGGL(k_schur_items<DD>, dim3(8 * cdiv(p->xcd_max_items, 4)), dim3(256), 0, h->stream,
+                         p->xcd_ptr, p->xcd_items, p->item_beg, p->item_end, p->pair_k, p->pair_k2, WS(L, G), WS(L, sch_part));
     hipLaunchKernelGGL(k_schur_assemble<DD>, dim3(C, cdiv(C, 2)), dim3(256), 0, h->stream, C, p->item_ptr,
                        WS(L, sch_part), WS(L, B), WS(L, red_S));
     hipLaunchKernelGGL(k_cam_reduce_chunks<DD>, dim3((unsigned)p->n_cchunks), dim3(256), 0, h->stream, p->cch_beg,

@@ -26,6 +26,8 @@ class BAStructure:
     item_ptr: np.ndarray    # [C(C+1)/2 + 1] int32: work items (<= ITEM_PAIRS pairs of ONE block) per block
     item_beg: np.ndarray    # [n_items] int32 ranges into pair_k / pair_k2
     item_end: np.ndarray    # [n_items] int32
+    xcd_ptr: np.ndarray     # [9] int32: items of block rows c = x (mod 8) are xcd_items[xcd_ptr[x]:xcd_ptr[x+1]]
+    xcd_items: np.ndarray   # [n_items] int32: item ids grouped by c mod 8 (an XCD keeps one camera's G in its L2)
     cch_ptr: np.ndarray     # [C+1] int32: chunks (<= CHUNK_OBS entries of cam_obs of ONE camera) per camera
     cch_beg: np.ndarray     # [n_cchunks] int32 ranges into cam_obs
     cch_end: np.ndarray     # [n_cchunks] int32
@@ -109,9 +111,17 @@ def build_structure(cam_idx, pt_idx, n_cams, n_pts):
     i32 = lambda a: np.ascontiguousarray(a, dtype=np.int32)
     item_ptr, item_beg, item_end = _split_ranges(blk_ptr, ITEM_PAIRS)
     cch_ptr, cch_beg, cch_end = _split_ranges(cam_ptr, CHUNK_OBS)
+    # block row of every item -> group by row mod 8 (stable: rows, then blocks, stay in order inside a group)
+    n_blk_row = np.arange(n_cams, 0, -1, dtype=np.int64)                 # row c holds blocks (c, c..C-1)
+    blk_row = np.repeat(np.arange(n_cams, dtype=np.int64), n_blk_row)
+    item_row = np.repeat(blk_row, np.diff(item_ptr))
+    xcd_items = np.argsort(item_row % 8, kind="stable")
+    xcd_ptr = np.zeros(9, dtype=np.int64)
+    np.cumsum(np.bincount(item_row % 8, minlength=8), out=xcd_ptr[1:])
     return BAStructure(int(n_cams), int(n_pts), i32(cam_idx), i32(pt_idx), i32(pt_ptr), i32(cam_ptr),
                        i32(cam_obs), i32(blk_ptr), i32(k[order]), i32(k2[order]),
-                       i32(item_ptr), i32(item_beg), i32(item_end), i32(cch_ptr), i32(cch_beg), i32(cch_end))
+                       i32(item_ptr), i32(item_beg), i32(item_end), i32(xcd_ptr), i32(xcd_items),
+                       i32(cch_ptr), i32(cch_beg), i32(cch_end))
 
 
 def partition_points(pt_ptr, world_size):
