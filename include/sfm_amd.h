@@ -174,6 +174,43 @@ int sfm_ba_read_scalars(sfm_handle h, const sfm_ba_problem* p, double* out_host)
 int sfm_dense_cholesky(sfm_handle h, double* a, int32_t n, int32_t* fail_flag);
 int sfm_dense_trsv(sfm_handle h, const double* l, int32_t n, double* b, int transpose);
 
+/* ------------------------------------------------------------------ driver-side rows either side of the path
+ * (SURVEY.md section 8f).  All three are batched over "segments" (one segment = one image pair), so the
+ * per-pair Python loops of the reference become one launch.  seg pointers are DEVICE int64 arrays.
+ */
+
+/* Replaces the dense [T,M,2] broadcast + np.where of find_2d3d_matches
+ * (/root/reference/utils/sfm_reconstruction.py:209-218): for every segment s, all pairs
+ * (track row i in [t_ptr[s], t_ptr[s+1]), correspondence m in [m_ptr[s], m_ptr[s+1])) with
+ * sqrt(dx*dx + dy*dy) < radius in float64, emitted segment-major, row-major (np.where order).
+ * track_xy [T][2], corr_xy [M][2] float64 (float32 pixels widened exactly, as NumPy's broadcast does).
+ * out_row / out_col: global row / correspondence indices, room for `capacity` pairs; pairs beyond the
+ * capacity are counted but not written.  *n_pairs: device int64 total.  workspace from
+ * sfm_assoc_workspace_bytes. */
+int sfm_assoc_workspace_bytes(int64_t n_rows, int64_t* bytes_host);
+int sfm_assoc_radius(sfm_handle h, const double* track_xy, const int64_t* t_ptr, const double* corr_xy,
+                     const int64_t* m_ptr, int32_t n_seg, int64_t n_rows, double radius,
+                     int32_t* out_row, int32_t* out_col, int64_t capacity, int64_t* n_pairs,
+                     void* workspace, int64_t workspace_bytes);
+
+/* Replaces the per-track cv2.triangulatePoints call + reprojection gate of triangulate_point
+ * (sfm_reconstruction.py:287-307) inside add_new_matches' loop (:381-385): two-view DLT (null vector of
+ * the 4x4 system x*P[2]-P[0], y*P[2]-P[1], by one-sided Jacobi SVD in float64), X = v[:3]/v[3], and
+ * valid[i] = 0 when either view reprojects further than max_err px (comparison `err > max_err`, so NaN
+ * passes exactly as in the reference).  proj [n_cams][12] row-major 3x4 K[R|t]; cam0/cam1 [n] index it;
+ * x0/x1 [n][2] float64 pixels.  X [n][3]; err [n][2] (optional, may be NULL). */
+int sfm_triangulate2(sfm_handle h, const double* proj, int32_t n_cams, const int32_t* cam0, const int32_t* cam1,
+                     const double* x0, const double* x1, int64_t n, double max_err,
+                     double* X, int32_t* valid, double* err);
+
+/* Replaces the per-match arithmetic of geometric_verification
+ * (/root/reference/utils/find_matches.py:160-174): epilines as cv2.computeCorrespondEpilines forms them
+ * (float64 accumulate, a^2+b^2 = 1, stored float32), the float32 symmetric epipolar distance and
+ * mask = err < threshold.  F [n_seg][9] float64; seg_ptr [n_seg+1]; pts1/pts2 [n][2] float32. */
+int sfm_epipolar_errors(sfm_handle h, const double* F, const int64_t* seg_ptr, int32_t n_seg,
+                        const float* pts1, const float* pts2, int64_t n, float threshold,
+                        float* err, uint8_t* mask);
+
 #ifdef __cplusplus
 }
 #endif

@@ -66,6 +66,10 @@ SIGNATURES = {
     "sfm_ba_read_scalars": (C.c_int, [vp, C.POINTER(BAProblem), C.POINTER(f64)]),
     "sfm_dense_cholesky": (C.c_int, [vp, vp, i32, vp]),
     "sfm_dense_trsv": (C.c_int, [vp, vp, i32, vp, C.c_int]),
+    "sfm_assoc_workspace_bytes": (C.c_int, [i64, C.POINTER(i64)]),
+    "sfm_assoc_radius": (C.c_int, [vp, vp, vp, vp, vp, i32, i64, f64, vp, vp, i64, vp, vp, i64]),
+    "sfm_triangulate2": (C.c_int, [vp, vp, i32, vp, vp, vp, vp, i64, f64, vp, vp, vp]),
+    "sfm_epipolar_errors": (C.c_int, [vp, vp, vp, i32, vp, vp, i64, C.c_float, vp, vp]),
 }
 
 _lib = None

@@ -7,7 +7,7 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
-SRC = [os.path.join(HERE, "csrc", f) for f in ("ctx.hip", "ba.hip", "dense.hip", "match.hip")]
+SRC = [os.path.join(HERE, "csrc", f) for f in ("ctx.hip", "ba.hip", "dense.hip", "match.hip", "driver.hip")]
 HDR = [os.path.join(HERE, "csrc", "common.h"), os.path.join(HERE, "csrc", "dense.h"), os.path.join(ROOT, "include", "sfm_amd.h")]
 LIB = os.path.join(HERE, "lib", "libsfm_amd.so")
 

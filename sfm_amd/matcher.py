@@ -1,6 +1,7 @@
 """Drop-in for the reference's `ImageMatcher.match_features`
 (/root/reference/utils/find_matches.py:141-155): brute-force kNN (k=2) + Lowe ratio test on
-the GPU through libsfm_amd.so.  No CPU fallback."""
+the GPU through libsfm_amd.so; `geometric_verification` (:157-214) comes from sfm_amd.driver.
+No CPU fallback."""
 from __future__ import annotations
 
 import ctypes as C
@@ -8,6 +9,7 @@ import ctypes as C
 import numpy as np
 
 from . import _lib
+from .driver import VerificationMixin
 
 
 class DMatch:
@@ -130,7 +132,7 @@ def match_arrays(desc1, desc2, ratio=0.75, metric="auto", device=0):
     return q.cpu().numpy(), t.cpu().numpy(), d.cpu().numpy()
 
 
-class ImageMatcher:
+class ImageMatcher(VerificationMixin):
     """`match_features` with the reference's call shape (find_matches.py:141).  The in-tree
     reference matches ORB bit strings with NORM_HAMMING and ratio 0.75; its shipped results come
     from SIFT / L2.  metric="auto" follows the descriptor type."""

@@ -10,9 +10,11 @@ stand-alone `StructureFromMotion` below.  The solve runs on the GPU; there is no
 from __future__ import annotations
 
 import logging
+from pathlib import Path
 
 import numpy as np
 
+from .driver import DriverMixin
 from .rotation import rodrigues, log_so3
 
 BUNDLE_ADJUST_FREQUENCY = 7      # sfm_reconstruction.py:19 (used by the reference's driver loop)
@@ -134,12 +136,17 @@ class BundleAdjustMixin:
                 'num_points': n_pts, 'num_cameras': n_cams}
 
 
-class StructureFromMotion(BundleAdjustMixin):
+class StructureFromMotion(BundleAdjustMixin, DriverMixin):
     """Minimal stand-alone holder of the reconstruction state (sfm_reconstruction.py:40-59) for
-    users who only need the hot path; the incremental driver loop stays the reference's."""
+    users who only need the hot path and the driver steps either side of it (sfm_amd.driver); the
+    incremental driver loop itself stays the reference's."""
 
     def __init__(self, data_dir=None, order="reference", cam_dim=10, device=0):
-        self.data_dir = data_dir
+        self.data_dir = Path(data_dir) if data_dir is not None else None
+        if self.data_dir is not None:                       # sfm_reconstruction.py:52-54
+            self.matches_dir = self.data_dir / 'matches'
+            self.fund_dir = self.data_dir / 'fundamental'
+            self.corr_dir = self.data_dir / 'correspondences'
         self.image_width = 1024
         self.image_height = 768
         self.constructed = []
@@ -150,3 +157,23 @@ class StructureFromMotion(BundleAdjustMixin):
         self.ba_order = order
         self.ba_cam_dim = cam_dim
         self.ba_device = device
+
+    def find_image_pairs(self, image_id):
+        """Pairs of `image_id` whose other image is already reconstructed (sfm_reconstruction.py:551-580):
+        names come from the match files on disk, in directory order."""
+        pairs = []
+        for path in self.matches_dir.glob('*.npz'):
+            pair = path.stem
+            if pair.endswith('_matches'):
+                pair = pair.replace('_matches', '')
+            if not pair.startswith('pair_'):
+                continue
+            try:
+                id1, id2 = map(int, pair.split('_')[1:3])
+            except (ValueError, IndexError):
+                logging.warning(f"Skipping file with unexpected name: {path}")
+                continue
+            other = id2 if id1 == image_id else id1 if id2 == image_id else None
+            if other is not None and f"{other:04d}.ppm" in self.constructed:
+                pairs.append(pair)
+        return pairs

@@ -9,7 +9,7 @@ cur = None; rows = {}
 for line in out.splitlines():
     m = re.search(r"Function Name: (\S+)", line)
     if m:
-        cur = subprocess.run(["c++filt", m.group(1)], capture_output=True, text=True).stdout.strip().split("(")[0]
+        cur = subprocess.run(["c++filt", m.group(1)], capture_output=True, text=True).stdout.strip().replace("(anonymous namespace)::", "").split("(")[0].replace("void ", "")
         rows[cur] = {}
         continue
     m = re.search(r"remark:\s+([A-Za-z /\[\]]+): (\d+)", line)
