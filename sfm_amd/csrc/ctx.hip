@@ -6,8 +6,15 @@ extern "C" const char* sfm_version(void) { return "sfm_amd 0.1 (gfx950)"; }
 extern "C" int sfm_create(int device, sfm_handle* out) {
   if (!out) return SFM_ERR_ARG;
   int ndev = 0;
-  if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) return SFM_ERR_HIP;
-  if (hipSetDevice(device) != hipSuccess) return SFM_ERR_HIP;
+  hipError_t e = hipGetDeviceCount(&ndev);
+  if (e != hipSuccess || device < 0 || device >= ndev) {
+    fprintf(stderr, "sfm_create: hipGetDeviceCount -> %s, %d device(s), asked for %d\n", hipGetErrorString(e), ndev, device);
+    return SFM_ERR_HIP;
+  }
+  if ((e = hipSetDevice(device)) != hipSuccess) {
+    fprintf(stderr, "sfm_create: hipSetDevice(%d) -> %s\n", device, hipGetErrorString(e));
+    return SFM_ERR_HIP;
+  }
   sfm_ctx* h = new sfm_ctx();
   h->device = device;
   h->stream = nullptr;
@@ -15,7 +22,8 @@ extern "C" int sfm_create(int device, sfm_handle* out) {
   h->pinned = nullptr;
   h->profiling = 0;
   memset(h->prof, 0, sizeof(h->prof));
-  if (hipHostMalloc((void**)&h->pinned, SFM_SC_COUNT * sizeof(double), hipHostMallocDefault) != hipSuccess) {
+  if ((e = hipHostMalloc((void**)&h->pinned, SFM_SC_COUNT * sizeof(double), hipHostMallocDefault)) != hipSuccess) {
+    fprintf(stderr, "sfm_create: hipHostMalloc -> %s\n", hipGetErrorString(e));
     delete h;
     return SFM_ERR_HIP;
   }

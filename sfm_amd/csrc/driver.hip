@@ -42,20 +42,23 @@ __device__ __forceinline__ int block_excl_scan(int v, int* s_w, int& total) {
 }
 
 // ------------------------------------------------------------------------------------------ association
-// One thread per track row; the block walks the segments its 256 rows touch (one, except at segment
-// boundaries) and stages that segment's correspondences through LDS 256 at a time, so the inner loop is a
-// broadcast LDS read + 5 fp64 VALU ops per pair.  d^2 < r2_hi is a safe prefilter; the kept test is the
-// reference's `sqrt(dx*dx + dy*dy) < radius` (np.linalg.norm(..., axis=2) < MATCHING_THRESHOLD).
+// One thread per (track row, column split).  The correspondence index is wave-uniform, so the compiler
+// keeps the correspondence in SGPRs (scalar loads, no LDS, no barrier) and a pair test is 5 fp64 VALU
+// instructions: dx, dy, dx*dx, fma -> d^2 (prefilter only, 1e-9 slack), compare.  Only candidates redo the
+// reference's arithmetic: `sqrt(dx*dx + dy*dy) < radius`, unfused, as np.linalg.norm(..., axis=2) <
+// MATCHING_THRESHOLD evaluates it.  Blocks walk the segments their 256 rows touch (one, except at segment
+// boundaries); blockIdx.y takes the y-th slice of each segment's correspondences so that a few hundred
+// row blocks still fill 256 CUs.  Pass 1 counts per (row, split), pass 2 writes at
+// blk_off + scan(row totals) + prefix over splits: np.where order, deterministic.
 template <bool FILL>
 __global__ __launch_bounds__(256) void k_assoc(const double2* __restrict__ tp, const int64_t* __restrict__ t_ptr,
                                                const double2* __restrict__ cp, const int64_t* __restrict__ m_ptr,
-                                               int n_seg, int64_t T, double radius, double r2_hi,
-                                               int* __restrict__ row_cnt, int* __restrict__ blk_cnt,
+                                               int n_seg, int64_t T, int nsplit, double radius, double r2_hi,
+                                               int* __restrict__ cnt_rs, int* __restrict__ blk_cnt,
                                                const int* __restrict__ blk_off, int* __restrict__ out_row,
                                                int* __restrict__ out_col, int64_t capacity) {
-  __shared__ double2 s_c[256];
   __shared__ int s_w[4];
-  const int tid = threadIdx.x;
+  const int tid = threadIdx.x, split = blockIdx.y;
   const int64_t row0 = (int64_t)blockIdx.x * 256;
   const int64_t i = row0 + tid;
   const bool active = i < T;
@@ -67,43 +70,69 @@ __global__ __launch_bounds__(256) void k_assoc(const double2* __restrict__ tp, c
   if (active) t = tp[i];
   int64_t off = 0;
   if (FILL) {
+    int row_total = 0, before = 0;
+    if (active)
+      for (int y = 0; y < nsplit; ++y) {
+        const int c = cnt_rs[i * nsplit + y];
+        row_total += c;
+        if (y < split) before += c;
+      }
     int total;
-    const int c = active ? row_cnt[i] : 0;
-    off = (int64_t)blk_off[blockIdx.x] + block_excl_scan(c, s_w, total);
+    off = (int64_t)blk_off[blockIdx.x] + block_excl_scan(row_total, s_w, total) + before;
   }
   int cnt = 0;
   for (int s = seg_first; s <= seg_last; ++s) {
     const int64_t m0 = m_ptr[s], m1 = m_ptr[s + 1];
-    const bool mine = (s == my_seg);
-    for (int64_t base = m0; base < m1; base += 256) {
-      __syncthreads();
-      if (base + tid < m1) s_c[tid] = cp[base + tid];
-      __syncthreads();
-      const int nt = (int)(m1 - base < 256 ? m1 - base : 256);
-      if (mine) {
-        for (int k = 0; k < nt; ++k) {
-          const double2 c = s_c[k];
-          const double dx = t.x - c.x, dy = t.y - c.y;
-          const double ss = dx * dx + dy * dy;
-          if (ss < r2_hi) {
-            if (sqrt(ss) < radius) {
-              if (FILL) {
-                if (off < capacity) { out_row[off] = (int)i; out_col[off] = (int)(base + k); }
-                ++off;
-              } else {
-                ++cnt;
-              }
+    const int64_t chunk = (m1 - m0 + nsplit - 1) / nsplit;
+    const int64_t b = m0 + chunk * split;
+    const int64_t e = (b + chunk < m1 ? b + chunk : m1);
+    if (s != my_seg) continue;
+    // 8 correspondences per trip: their loads are issued together (s_load_dwordx16 x2), the prefilter keeps
+    // only min d^2, and the exact test reruns the 8 only when some lane has a candidate (rare)
+    int64_t m = b;
+    for (; m + 8 <= e; m += 8) {
+      double2 c[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) c[k] = cp[m + k];
+      double dmin = r2_hi;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const double dx = t.x - c[k].x, dy = t.y - c[k].y;
+        dmin = fmin(dmin, __builtin_fma(dx, dx, dy * dy));
+      }
+      if (dmin < r2_hi) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          const double dx = t.x - c[k].x, dy = t.y - c[k].y;
+          if (sqrt(dx * dx + dy * dy) < radius) {
+            if (FILL) {
+              if (off < capacity) { out_row[off] = (int)i; out_col[off] = (int)(m + k); }
+              ++off;
+            } else {
+              ++cnt;
             }
           }
         }
       }
     }
+    for (; m < e; ++m) {
+      const double2 c = cp[m];
+      const double dx = t.x - c.x, dy = t.y - c.y;
+      if (sqrt(dx * dx + dy * dy) < radius) {
+        if (FILL) {
+          if (off < capacity) { out_row[off] = (int)i; out_col[off] = (int)m; }
+          ++off;
+        } else {
+          ++cnt;
+        }
+      }
+    }
   }
   if (!FILL) {
-    if (active) row_cnt[i] = cnt;
+    if (active) cnt_rs[i * nsplit + split] = cnt;
     int total;
     (void)block_excl_scan(cnt, s_w, total);
-    if (tid == 0) blk_cnt[blockIdx.x] = total;
+    if (tid == 0 && total) atomicAdd(&blk_cnt[blockIdx.x], total);
   }
 }
 
@@ -256,10 +285,17 @@ __global__ __launch_bounds__(256) void k_epipolar(const double* __restrict__ F, 
 }  // namespace
 
 // ================================================================================================ C ABI
+static int assoc_nsplit(int64_t n_rows) {
+  // enough (row block, split) workgroups for ~8 waves per SIMD on 256 CUs
+  const int64_t nblk = (n_rows + 255) / 256;
+  int64_t ns = (2048 + nblk - 1) / nblk;
+  return (int)(ns < 1 ? 1 : ns > 32 ? 32 : ns);
+}
+
 extern "C" int sfm_assoc_workspace_bytes(int64_t n_rows, int64_t* bytes_host) {
   if (!bytes_host || n_rows < 0) return SFM_ERR_ARG;
   const int64_t nblk = (n_rows + 255) / 256;
-  *bytes_host = align_up(n_rows * 4, 256) + 2 * align_up(nblk * 4, 256) + 256;
+  *bytes_host = align_up(n_rows * assoc_nsplit(n_rows) * 4, 256) + 2 * align_up(nblk * 4, 256) + 256;
   return SFM_OK;
 }
 
@@ -268,7 +304,7 @@ extern "C" int sfm_assoc_radius(sfm_handle h, const double* track_xy, const int6
                                 int32_t* out_row, int32_t* out_col, int64_t capacity, int64_t* n_pairs,
                                 void* workspace, int64_t workspace_bytes) {
   if (!h) return SFM_ERR_ARG;
-  if (!n_pairs || n_rows < 0 || n_seg < 0 || capacity < 0 || n_rows > 0x7fffffffLL)
+  if (!n_pairs || n_rows < 0 || n_seg < 0 || capacity < 0 || n_rows > 0x3fffffffLL)
     return sfm_fail(h, SFM_ERR_ARG, "sfm_assoc_radius", "bad argument");
   if (n_rows == 0 || n_seg == 0) {
     SFM_HIP(h, hipMemsetAsync(n_pairs, 0, sizeof(int64_t), h->stream));
@@ -280,18 +316,20 @@ extern "C" int sfm_assoc_radius(sfm_handle h, const double* track_xy, const int6
   sfm_assoc_workspace_bytes(n_rows, &need);
   if (workspace_bytes < need) return sfm_fail(h, SFM_ERR_WORKSPACE, "sfm_assoc_radius", "workspace too small");
   const int nblk = (int)cdiv(n_rows, 256);
+  const int nsplit = assoc_nsplit(n_rows);
   char* ws = (char*)workspace;
-  int* row_cnt = (int*)ws;                 ws += align_up(n_rows * 4, 256);
+  int* cnt_rs = (int*)ws;                  ws += align_up(n_rows * nsplit * 4, 256);
   int* blk_cnt = (int*)ws;                 ws += align_up((int64_t)nblk * 4, 256);
   int* blk_off = (int*)ws;
   const double r2_hi = radius * radius * (1.0 + 1e-9) + DBL_MIN;
-  hipLaunchKernelGGL((k_assoc<false>), dim3(nblk), dim3(256), 0, h->stream, (const double2*)track_xy, t_ptr,
-                     (const double2*)corr_xy, m_ptr, n_seg, n_rows, radius, r2_hi, row_cnt, blk_cnt,
+  SFM_HIP(h, hipMemsetAsync(blk_cnt, 0, (size_t)nblk * 4, h->stream));
+  hipLaunchKernelGGL((k_assoc<false>), dim3(nblk, nsplit), dim3(256), 0, h->stream, (const double2*)track_xy, t_ptr,
+                     (const double2*)corr_xy, m_ptr, n_seg, n_rows, nsplit, radius, r2_hi, cnt_rs, blk_cnt,
                      (const int*)nullptr, (int*)nullptr, (int*)nullptr, (int64_t)0);
   hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(256), 0, h->stream, nblk, blk_cnt, blk_off, n_pairs);
   if (capacity > 0)
-    hipLaunchKernelGGL((k_assoc<true>), dim3(nblk), dim3(256), 0, h->stream, (const double2*)track_xy, t_ptr,
-                       (const double2*)corr_xy, m_ptr, n_seg, n_rows, radius, r2_hi, row_cnt, blk_cnt,
+    hipLaunchKernelGGL((k_assoc<true>), dim3(nblk, nsplit), dim3(256), 0, h->stream, (const double2*)track_xy, t_ptr,
+                       (const double2*)corr_xy, m_ptr, n_seg, n_rows, nsplit, radius, r2_hi, cnt_rs, blk_cnt,
                        (const int*)blk_off, out_row, out_col, capacity);
   SFM_LAUNCH_CHECK(h, "sfm_assoc_radius");
   return SFM_OK;

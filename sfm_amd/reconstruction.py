@@ -15,6 +15,7 @@ from pathlib import Path
 import numpy as np
 
 from .driver import DriverMixin
+from .interchange import ReconstructionIOMixin
 from .rotation import rodrigues, log_so3
 
 BUNDLE_ADJUST_FREQUENCY = 7      # sfm_reconstruction.py:19 (used by the reference's driver loop)
@@ -136,7 +137,7 @@ class BundleAdjustMixin:
                 'num_points': n_pts, 'num_cameras': n_cams}
 
 
-class StructureFromMotion(BundleAdjustMixin, DriverMixin):
+class StructureFromMotion(BundleAdjustMixin, DriverMixin, ReconstructionIOMixin):
     """Minimal stand-alone holder of the reconstruction state (sfm_reconstruction.py:40-59) for
     users who only need the hot path and the driver steps either side of it (sfm_amd.driver); the
     incremental driver loop itself stays the reference's."""
