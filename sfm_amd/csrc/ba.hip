@@ -1035,8 +1035,8 @@ extern "C" int sfm_ba_schur_solve(sfm_handle h, const sfm_ba_problem* p, double 
   sfm_prof_end(h, SFM_PROF_CHOL);
   sfm_prof_begin(h, SFM_PROF_TRSV);
   // p_c = -L^-T (L^-1 r)
-  hipLaunchKernelGGL(k_copy_neg, dim3(cdiv(n, 256)), dim3(256), 0, h->stream, S + (size_t)n * n, WS(L, tvec), n, -1.0);
-  rc = dense_trsv(h, S, n, dw, WS(L, tvec), WS(L, pc), 1); if (rc) return rc;
+  hipLaunchKernelGGL(k_copy_neg, dim3(cdiv(n, 256)), dim3(256), 0, h->stream, dw.Lm + (size_t)n * n, WS(L, tvec), n, -1.0);
+  rc = dense_trsv(h, n, dw, WS(L, tvec), WS(L, pc), 1); if (rc) return rc;
   sfm_prof_end(h, SFM_PROF_TRSV);
   sfm_prof_begin(h, SFM_PROF_BACKSUB);
   DISPATCH_D(D, hipLaunchKernelGGL(k_obs_Gtp<DD>, dim3(cdiv(N * 3, 256)), dim3(256), 0, h->stream, N * 3,
@@ -1067,7 +1067,7 @@ extern "C" int sfm_ba_finish_solve(sfm_handle h, const sfm_ba_problem* p, int wa
     // rhs2 = p_c - W C_a^-1 p_p ;  y = L^-1 rhs2
     sfm_prof_begin(h, SFM_PROF_TRSV);
     hipLaunchKernelGGL(k_add_vec, dim3(cdiv(n, 256)), dim3(256), 0, h->stream, WS(L, pc), WS(L, red_q), WS(L, tvec), n);
-    rc = dense_trsv(h, WS(L, red_S), n, dw, WS(L, tvec), WS(L, y), 0); if (rc) return rc;
+    rc = dense_trsv(h, n, dw, WS(L, tvec), WS(L, y), 0); if (rc) return rc;
     sfm_prof_end(h, SFM_PROF_TRSV);
   }
   hipLaunchKernelGGL(k_finish_solve, dim3(1), dim3(256), 0, h->stream, n, WS(L, pc), WS(L, red_q), WS(L, y),

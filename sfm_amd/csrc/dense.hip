@@ -40,19 +40,22 @@ __device__ __forceinline__ double wave_sum_d(double v) {
 
 int64_t dense_ws_doubles(int n) {
   const int64_t nb = (n + 127) / 128;
-  return align_up((int64_t)(n + 1) * 64, 32) + 64 * 64 + 32 + 2 * nb * 128 * 128 + nb * 2 * 64 * 64 + nb * 64 * 64 + 32;
+  return align_up((int64_t)(n + 1) * 64, 32) + 2 * 64 * 64 + 32 + 2 * nb * 128 * 128 + nb * 2 * 64 * 64 + nb * 64 * 64 + 32 +
+         align_up(nb, 64) + align_up((int64_t)(n + 1) * n, 32);
 }
 void dense_ws_carve(double* base, int n, DenseWs* w) {
   const int64_t nb = (n + 127) / 128;
   double* p = base;
   w->panel = p; p += align_up((int64_t)(n + 1) * 64, 32);
-  w->Ld = p; p += 64 * 64;
+  w->Ld = p; p += 2 * 64 * 64;
   w->rd = p; p += 32;
   w->Dinv = p; p += nb * 128 * 128;
   w->DinvT = p; p += nb * 128 * 128;
   w->inv64 = p; p += nb * 2 * 64 * 64;
   w->tmp = p; p += nb * 64 * 64;
-  w->flag = (int*)p;
+  w->flag = (int*)p; p += 32;
+  w->tflag = (int*)p; p += align_up(nb, 64);
+  w->Lm = p;
 }
 
 // ------------------------------------------------------------------------------------ Cholesky
@@ -178,10 +181,14 @@ __device__ __forceinline__ v4d mm32_tile(const double* __restrict__ pa, int lda,
   return acc;
 }
 
-// Factor + invert the tile in c.sM.  store_L(r, c, v) / store_Li(r, c, v) receive every lower-triangular
-// entry of L and L^-1 (64x64 coordinates); *ok is cleared on a non-positive pivot.  nb = valid size.
-template <class FL, class FI>
-__device__ __forceinline__ void crit64_run(const Crit64& c, int tid, FL store_L, FI store_Li, int* __restrict__ fail) {
+// Factor the tile in c.sM and invert its two 32x32 diagonal blocks:  [A11 .; A21 A22] = [L11 0; L21 L22] [..]^T.
+// store_L(r, c, v) receives every lower-triangular entry of L (64x64 coordinates), store_Li the entries of
+// L11^-1 (r, c < 32) and L22^-1 (r, c >= 32), store_L21 the raw block L21 (r >= 32, c < 32).  The full 64x64
+// inverse is NOT formed here: the trailing rows are solved in two 32-wide stages (trsm_rows16), which keeps the
+// two products L21 L11^-1 and L22^-1 (...) off the serial chain; k_inv64_fix builds them later for the solves.
+template <class FL, class FI, class F21>
+__device__ __forceinline__ void crit64_lite(const Crit64& c, int tid, FL store_L, FI store_Li, F21 store_L21,
+                                            int* __restrict__ fail) {
   const int lane = tid & 63, w = tid >> 6;
   const int i = lane & 31, h = lane >> 5;
   const int tr = w >> 1, tc = w & 1;
@@ -206,22 +213,17 @@ __device__ __forceinline__ void crit64_run(const Crit64& c, int tid, FL store_L,
 #pragma unroll
     for (int q = 0; q < 4; ++q) c.sM[(32 + tr * 16 + kq + 4 * q) * LDM + tc * 16 + r16] = acc[q];
   }
-  __syncthreads();
-  // ---- P2b: T = L21 Li11 ;  P3: A22 -= L21 L21^T
-  {
-    const v4d t = mm32_tile<false>(c.sM + 32 * LDM, LDM, c.sLi11, LDL, tr, tc, lane);
-    const v4d u = mm32_tile<true>(c.sM + 32 * LDM, LDM, c.sM + 32 * LDM, LDM, tr, tc, lane);
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const int r = tr * 16 + kq + 4 * q, cc = tc * 16 + r16;
-      c.sT[r * LDL + cc] = t[q];
-      c.sM[(32 + r) * LDM + 32 + cc] -= u[q];
-    }
-  }
-  // L11 / Li11 leave LDS now: sC is reused by the second factor, sLi11 later receives Li21
+  // L11 / Li11 leave LDS now: sC is reused by the second factor
   for (int e = tid; e < 32 * 32; e += 256) {
     const int r = e >> 5, cc = e & 31;
     if (cc <= r) { store_L(r, cc, c.sC[cc * 32 + r]); store_Li(r, cc, c.sLi11[r * LDL + cc]); }
+  }
+  __syncthreads();
+  // ---- P3: A22 -= L21 L21^T
+  {
+    const v4d u = mm32_tile<true>(c.sM + 32 * LDM, LDM, c.sM + 32 * LDM, LDM, tr, tc, lane);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) c.sM[(32 + tr * 16 + kq + 4 * q) * LDM + 32 + tc * 16 + r16] -= u[q];
   }
   __syncthreads();
   // ---- P4: A22 = L22 L22^T, Li22
@@ -234,23 +236,21 @@ __device__ __forceinline__ void crit64_run(const Crit64& c, int tid, FL store_L,
     wave_inv32_follow(c.sC, c.srd + 32, &c.flag[1], lane, c.sLi22, LDL);
   }
   __syncthreads();
-  // ---- P5: Li21 = -Li22 T
-  {
-    const v4d acc = mm32_tile<false>(c.sLi22, LDL, c.sT, LDL, tr, tc, lane);
-#pragma unroll
-    for (int q = 0; q < 4; ++q) store_Li(32 + tr * 16 + kq + 4 * q, tc * 16 + r16, -acc[q]);
-  }
   for (int e = tid; e < 32 * 32; e += 256) {
     const int r = e >> 5, cc = e & 31;
-    store_L(32 + r, cc, c.sM[(32 + r) * LDM + cc]);                          // L21 (full block)
+    const double l21 = c.sM[(32 + r) * LDM + cc];
+    store_L(32 + r, cc, l21);
+    store_L21(32 + r, cc, l21);
     if (cc <= r) { store_L(32 + r, 32 + cc, c.sC[cc * 32 + r]); store_Li(32 + r, 32 + cc, c.sLi22[r * LDL + cc]); }
   }
 }
 
-// Factor the first 64x64 diagonal block in place; its inverse goes to Li (64x64 row-major, zeros above the
-// diagonal) for the panel kernel and to inv64 for the triangular solves.
-__global__ __launch_bounds__(256) void k_chol_diag(double* __restrict__ A, int n, double* __restrict__ Li,
-                                                   double* __restrict__ inv64, int* __restrict__ fail) {
+// Step data of one diagonal block as the step kernel reads it: D [64][64] row-major =
+// [Li11 0; L21 Li22] (32x32 quadrants; identity-padded when the block is short).
+// Factor the first 64x64 diagonal block: L -> Lm, step data -> D, diagonal 32-block inverses -> inv64.
+__global__ __launch_bounds__(256) void k_chol_first(const double* __restrict__ A, double* __restrict__ Lm, int n,
+                                                    double* __restrict__ D, double* __restrict__ inv64,
+                                                    int* __restrict__ fail) {
   __shared__ double smem[CRIT64_DOUBLES + 6];     // static: with `extern __shared__` hipcc needs 256 + 68 registers here
   const Crit64 c = crit64_carve(smem);
   const int tid = threadIdx.x;
@@ -258,78 +258,115 @@ __global__ __launch_bounds__(256) void k_chol_diag(double* __restrict__ A, int n
   for (int e = tid; e < 64 * 64; e += 256) {
     const int r = e >> 6, cc = e & 63;
     c.sM[r * LDM + cc] = (r < nb && cc < nb) ? ((cc <= r) ? A[(size_t)r * n + cc] : 0.0) : ((r == cc) ? 1.0 : 0.0);
-    Li[e] = 0.0;
+    D[e] = 0.0;
     inv64[e] = 0.0;
   }
   __syncthreads();
-  crit64_run(c, tid,
-             [&](int r, int cc, double v) { if (r < nb && cc < nb) A[(size_t)r * n + cc] = v; },
-             [&](int r, int cc, double v) { Li[r * 64 + cc] = v; inv64[r * 64 + cc] = v; }, fail);
+  crit64_lite(c, tid,
+              [&](int r, int cc, double v) { if (r < nb && cc < nb) Lm[(size_t)r * n + cc] = v; },
+              [&](int r, int cc, double v) { D[r * 64 + cc] = v; inv64[r * 64 + cc] = v; },
+              [&](int r, int cc, double v) { D[r * 64 + cc] = v; }, fail);
 }
 
-// Rows below the diagonal block:  X = A_panel L_jj^-T  as a 64-deep product with the explicit inverse
-// Li = L_jj^-1 (from the look-ahead workgroup):  X[r][c] = sum_{k<=c} A[r][k] Li[c][k]  on
-// v_mfma_f64_16x16x4_f64, wave w = 16 rows, four 16-column tiles.  64 rows per workgroup.
-__global__ __launch_bounds__(256) void k_chol_panel(double* __restrict__ A, int n, int nrows, int j0,
-                                                    double* __restrict__ panel, const double* __restrict__ Li) {
-  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-  const int nb = (n - j0) < 64 ? (n - j0) : 64;
-  const int j1 = j0 + nb;
+// X = A_rows L_jj^-T for the 16 rows [row, row + 16) of this wavefront, 64 columns, in two 32-wide stages on
+// v_mfma_f64_16x16x4_f64:   X1 = A1 Li11^T;   X2 = (A2 - X1 L21^T) Li22^T.
+// sD = step data [64][LDM] in LDS; dst = this wave's 16 rows of an LDS tile [.][LDM]: X lands there (the MFMA
+// result layout has to become an A-operand layout between the stages, which is a round trip through dst) and
+// in x[4] (C layout: row = kq + 4 i, column = 16 t + r16).  All four wavefronts call this together
+// (__syncthreads inside).  Rows >= nrows and columns >= nb read as zero.
+__device__ __forceinline__ void trsm_rows16(const double* __restrict__ A, int n, int nrows, int j0, int nb, int row,
+                                            const double* __restrict__ sD, double* __restrict__ dst, int lane,
+                                            v4d (&x)[4]) {
   const int r16 = lane & 15, kq = lane >> 4;
-  const int rbase = j1 + blockIdx.x * 64 + w * 16;     // first global row of this wave
-  if (rbase >= nrows) return;
-  const int arow = rbase + r16;
+  const int arow = row + r16;
   const bool aok = arow < nrows;
   const double* ap = A + (size_t)arow * n + j0;
-  // the 16 A-operand values of this lane (k = 4 s + kq), issued together
-  double av[16];
+  double a1[8];
 #pragma unroll
-  for (int s4 = 0; s4 < 16; ++s4) av[s4] = (aok && (4 * s4 + kq) < nb) ? ap[4 * s4 + kq] : 0.0;
-  v4d acc[4];
+  for (int s4 = 0; s4 < 8; ++s4) a1[s4] = (aok && (4 * s4 + kq) < nb) ? ap[4 * s4 + kq] : 0.0;
+  double a2c[2][4];                               // A2 in the result layout
 #pragma unroll
-  for (int t = 0; t < 4; ++t) acc[t] = (v4d){0.0, 0.0, 0.0, 0.0};
-  // Li is lower triangular: column tile t (columns 16 t ..) only has k <= 16 t + 15; B operand read from L2
-#pragma unroll
-  for (int t = 0; t < 4; ++t) {
-    const double* bp = Li + (size_t)(t * 16 + r16) * 64 + kq;
-#pragma unroll
-    for (int s4 = 0; s4 < 4 * (t + 1); ++s4)
-      acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[s4], bp[4 * s4], acc[t], 0, 0, 0);
-  }
-#pragma unroll
-  for (int t = 0; t < 4; ++t)
+  for (int t = 0; t < 2; ++t)
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      const int row = rbase + kq + 4 * i, col = t * 16 + r16;
-      if (row < nrows) {
-        const double v = (col < nb) ? acc[t][i] : 0.0;
-        if (col < nb) A[(size_t)row * n + j0 + col] = v;
-        panel[(size_t)(row - j1) * 64 + col] = v;
-      }
+      const int gr = row + kq + 4 * i, col = 32 + 16 * t + r16;
+      a2c[t][i] = (gr < nrows && col < nb) ? A[(size_t)gr * n + j0 + col] : 0.0;
     }
+#pragma unroll
+  for (int t = 0; t < 4; ++t) x[t] = (v4d){0.0, 0.0, 0.0, 0.0};
+  // stage 1: Li11 is lower triangular, column tile t only has k <= 16 t + 15
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    const double* bp = sD + (t * 16 + r16) * LDM + kq;
+#pragma unroll
+    for (int s4 = 0; s4 < 4 * (t + 1); ++s4) x[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[s4], bp[4 * s4], x[t], 0, 0, 0);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) dst[(kq + 4 * i) * LDM + t * 16 + r16] = x[t][i];
+  }
+  __syncthreads();
+  // stage 2a: A2' = A2 - X1 L21^T
+  {
+    double xa[8];
+#pragma unroll
+    for (int s4 = 0; s4 < 8; ++s4) xa[s4] = dst[r16 * LDM + 4 * s4 + kq];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      v4d u = {0.0, 0.0, 0.0, 0.0};
+      const double* bp = sD + (32 + t * 16 + r16) * LDM + kq;
+#pragma unroll
+      for (int s4 = 0; s4 < 8; ++s4) u = __builtin_amdgcn_mfma_f64_16x16x4f64(xa[s4], bp[4 * s4], u, 0, 0, 0);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) dst[(kq + 4 * i) * LDM + 32 + t * 16 + r16] = a2c[t][i] - u[i];
+    }
+  }
+  __syncthreads();
+  // stage 2b: X2 = A2' Li22^T
+  {
+    double xa[8];
+#pragma unroll
+    for (int s4 = 0; s4 < 8; ++s4) xa[s4] = dst[r16 * LDM + 32 + 4 * s4 + kq];
+    __syncthreads();                              // every lane has its operands before the tile is overwritten
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const double* bp = sD + (32 + t * 16 + r16) * LDM + 32 + kq;
+#pragma unroll
+      for (int s4 = 0; s4 < 4 * (t + 1); ++s4)
+        x[2 + t] = __builtin_amdgcn_mfma_f64_16x16x4f64(xa[s4], bp[4 * s4], x[2 + t], 0, 0, 0);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) dst[(kq + 4 * i) * LDM + 32 + t * 16 + r16] = x[2 + t][i];
+    }
+  }
+  __syncthreads();
 }
 
-// Rank-64 update of the trailing lower 64x64 tiles on v_mfma_f64_16x16x4_f64 (panel rows staged in LDS in two
-// 32-deep halves, row stride 34 doubles = conflict-free ds_read_b64).  Look-ahead: the workgroup of tile
-// (0,0) then factors AND inverts the next 64x64 diagonal block in LDS (crit64_run) and publishes L^-1 for the
-// next panel kernel, so the serial factorisation chain never waits for a kernel of its own.
-__global__ __launch_bounds__(256) void k_chol_update(double* __restrict__ A, int n, int nrows, int j1,
-                                                     const double* __restrict__ panel, double* __restrict__ Li,
-                                                     double* __restrict__ inv64_next, int* __restrict__ fail) {
-  __shared__ double smem[CRIT64_DOUBLES + 6];     // 68.7 KB static (gfx950 allows up to 160 KB): 2 workgroups per CU
+// One step of the blocked factorisation = ONE kernel: for the 64-column panel at j0 (diagonal block already
+// factored, its step data in D) every lower-triangular 64x64 tile (ti, tj) of the trailing matrix
+//   1. solves its own panel rows  X_I = A[I, j0:j1] L_jj^-T  and X_J (trsm_rows16; recomputing them per tile
+//      costs a few microseconds of MFMA time and removes the separate panel kernel from the serial chain),
+//   2. tiles of the first tile column (tj == 0) write X_I to the factor Lm,
+//   3. A[I, J] -= X_I X_J^T  (rank-64 update from LDS, row stride 66 doubles = conflict-free ds_read_b64),
+//   4. LOOK-AHEAD: the workgroup of tile (0,0) then factors the next diagonal block in LDS (crit64_lite) and
+//      publishes its step data to Dn for the next launch, so the serial chain never waits for a kernel of its own.
+// A's panel columns are only read here (never overwritten), which is what makes step 1 race-free.
+__global__ __launch_bounds__(256) void k_chol_step(double* __restrict__ A, double* __restrict__ Lm, int n, int nrows,
+                                                   int j0, const double* __restrict__ D, double* __restrict__ Dn,
+                                                   double* __restrict__ inv64_next, int* __restrict__ fail) {
+  __shared__ double smem[CRIT64_DOUBLES + 6 + 64 * LDM];     // 102.5 KB static (gfx950 allows up to 160 KB)
   double* sI = smem;                 // [64][LDM]
-  double* sJ = smem + 64 * LDM;      // [64][LDM]   (the factor's buffers later reuse this space)
+  double* sJ = smem + 64 * LDM;      // [64][LDM]   (the factor's buffers later reuse sI/sJ)
+  double* sD = smem + CRIT64_DOUBLES + 6;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   // 1-D grid over the lower-triangular tiles only: block b -> (ti, tj), tj <= ti, b = ti (ti + 1) / 2 + tj
-  const int tid = threadIdx.x;
   int ti = (int)((sqrtf(8.0f * (float)blockIdx.x + 1.0f) - 1.0f) * 0.5f);
   while ((ti + 1) * (ti + 2) / 2 <= (int)blockIdx.x) ++ti;
   while (ti * (ti + 1) / 2 > (int)blockIdx.x) --ti;
   const int tj = (int)blockIdx.x - ti * (ti + 1) / 2;
-  const int lane = tid & 63, w = tid >> 6;
+  const int nb = (n - j0) < 64 ? (n - j0) : 64;
+  const int j1 = j0 + nb;
   const int rem_r = nrows - j1, rem_c = n - j1;
   const int I0 = ti * 64, J0 = tj * 64;
-  // prefetch the C tile this lane updates (rows 16 w + (lane>>4) + 4 i, cols 16 t + (lane&15))
   const int col16 = lane & 15, rq = lane >> 4;
+  // prefetch the C tile this lane updates (rows 16 w + (lane>>4) + 4 i, cols 16 t + (lane&15))
   double cv[4][4];
 #pragma unroll
   for (int t = 0; t < 4; ++t)
@@ -338,27 +375,40 @@ __global__ __launch_bounds__(256) void k_chol_update(double* __restrict__ A, int
       const int gr = I0 + w * 16 + rq + 4 * i, gcol = J0 + t * 16 + col16;
       cv[t][i] = (gr < rem_r && gcol < rem_c && gcol <= gr) ? A[(size_t)(j1 + gr) * n + j1 + gcol] : 0.0;
     }
+  for (int e = tid; e < 64 * 64; e += 256) sD[(e >> 6) * LDM + (e & 63)] = D[e];
+  __syncthreads();
+  v4d xi[4], xj[4];
+  trsm_rows16(A, n, nrows, j0, nb, j1 + I0 + w * 16, sD, sI + w * 16 * LDM, lane, xi);
+  if (tj == 0) {
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int gr = j1 + I0 + w * 16 + rq + 4 * i, col = t * 16 + col16;
+        if (gr < nrows && col < nb) Lm[(size_t)gr * n + j0 + col] = xi[t][i];
+      }
+  }
+  if (rem_c <= 0) return;                          // only the bordered row was left: nothing to update
+  const double* sJr = sI;
+  if (ti != tj) {
+    trsm_rows16(A, n, nrows, j0, nb, j1 + J0 + w * 16, sD, sJ + w * 16 * LDM, lane, xj);
+    sJr = sJ;
+  }
   v4d acc[4];
 #pragma unroll
   for (int t = 0; t < 4; ++t) acc[t] = (v4d){0.0, 0.0, 0.0, 0.0};
-  for (int i = tid; i < 64 * 64; i += 256) {
-    const int r = i >> 6, c = i & 63;
-    sI[r * LDM + c] = (I0 + r < rem_r) ? panel[(size_t)(I0 + r) * 64 + c] : 0.0;
-    sJ[r * LDM + c] = (J0 + r < rem_c) ? panel[(size_t)(J0 + r) * 64 + c] : 0.0;
-  }
-  __syncthreads();
 #pragma unroll 4
   for (int k0 = 0; k0 < 64; k0 += 4) {
     const double a = sI[(w * 16 + col16) * LDM + k0 + rq];
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
-      const double b = sJ[(t * 16 + col16) * LDM + k0 + rq];
+      const double b = sJr[(t * 16 + col16) * LDM + k0 + rq];
       acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[t], 0, 0, 0);
     }
   }
   const bool crit = (ti == 0 && tj == 0);
   const int nbn = rem_c < 64 ? rem_c : 64;        // size of the next diagonal block (rem_c >= 1 here)
-  if (crit) __syncthreads();                       // staging is about to become the factor's tile buffer
+  if (crit) __syncthreads();                       // the tiles are about to become the factor's buffers
   const Crit64 c = crit64_carve(smem);
 #pragma unroll
   for (int t = 0; t < 4; ++t)
@@ -374,17 +424,42 @@ __global__ __launch_bounds__(256) void k_chol_update(double* __restrict__ A, int
       else if (inside) A[(size_t)(j1 + gr) * n + j1 + gcol] = v;
     }
   if (!crit) return;
-  // identity outside the valid corner, zero the strict upper part the factor reads as "<= i" only
+  // identity outside the valid corner; clear what the stores below do not touch
   for (int e = tid; e < 64 * 64; e += 256) {
     const int r = e >> 6, cc = e & 63;
     if (r >= nbn || cc >= nbn) c.sM[r * LDM + cc] = (r == cc) ? 1.0 : 0.0;
-    Li[e] = 0.0;
+    Dn[e] = 0.0;
     inv64_next[e] = 0.0;
   }
   __syncthreads();
-  crit64_run(c, tid,
-             [&](int r, int cc, double v) { if (r < nbn && cc < nbn) A[(size_t)(j1 + r) * n + j1 + cc] = v; },
-             [&](int r, int cc, double v) { Li[r * 64 + cc] = v; inv64_next[r * 64 + cc] = v; }, fail);
+  crit64_lite(c, tid,
+              [&](int r, int cc, double v) { if (r < nbn && cc < nbn) Lm[(size_t)(j1 + r) * n + j1 + cc] = v; },
+              [&](int r, int cc, double v) { Dn[r * 64 + cc] = v; inv64_next[r * 64 + cc] = v; },
+              [&](int r, int cc, double v) { Dn[r * 64 + cc] = v; }, fail);
+}
+
+// Off-diagonal quadrant of each 64x64 diagonal-block inverse, for the triangular solves:
+// inv64[b] holds [Li11 0; 0 Li22] after the factorisation; Li21 = -Li22 (L21 Li11).  One workgroup per block.
+__global__ __launch_bounds__(256) void k_inv64_fix(const double* __restrict__ Lm, int n, double* __restrict__ inv64) {
+  __shared__ double sA[32 * LDL], sB[32 * LDL], sC2[32 * LDL], sT[32 * LDL];
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int r0 = b * 64;
+  double* M = inv64 + (size_t)b * 64 * 64;
+  for (int e = tid; e < 32 * 32; e += 256) {
+    const int r = e >> 5, cc = e & 31;
+    sA[r * LDL + cc] = (r0 + 32 + r < n) ? Lm[(size_t)(r0 + 32 + r) * n + r0 + cc] : 0.0;     // L21
+    sB[r * LDL + cc] = M[r * 64 + cc];                                                       // Li11
+    sC2[r * LDL + cc] = M[(32 + r) * 64 + 32 + cc];                                          // Li22
+  }
+  __syncthreads();
+  const int tr = w >> 1, tc = w & 1, kq = lane >> 4, r16 = lane & 15;
+  const v4d t = mm32_tile<false>(sA, LDL, sB, LDL, tr, tc, lane);
+#pragma unroll
+  for (int q = 0; q < 4; ++q) sT[(tr * 16 + kq + 4 * q) * LDL + tc * 16 + r16] = t[q];
+  __syncthreads();
+  const v4d m = mm32_tile<false>(sC2, LDL, sT, LDL, tr, tc, lane);
+#pragma unroll
+  for (int q = 0; q < 4; ++q) M[(32 + tr * 16 + kq + 4 * q) * 64 + tc * 16 + r16] = -m[q];
 }
 
 // ------------------------------------------------------------------------------------ diagonal-block inverses
@@ -524,32 +599,143 @@ __global__ __launch_bounds__(256) void k_trsv_step(const double* __restrict__ L,
   }
 }
 
+// Whole triangular solve in ONE launch (n <= 128 * TRSV_FLOW_MAX_BLOCKS): workgroup g owns the 128 unknowns of
+// block g, keeps Dinv_g(^T) in LDS, and consumes the other blocks' solutions as they are published.  There is
+// no flag: xout is pre-filled with an all-ones bit pattern (a NaN no arithmetic produces), producers store their
+// solution with agent-scope atomic stores and each consumer thread polls ITS element with agent-scope atomic
+// loads, so a hand-off is one L2 round trip.  After its last dependency a block only has one 128x128
+// product (from registers) + the Dinv product (from LDS) left: the chain is n/128 hand-offs, not n/128 launches.
+// Every working workgroup must be resident at once: one per CU (134 KB of LDS).  Placement: workgroups go
+// round-robin over the 8 XCDs, so worker p sits at blockIdx 8 p + xcd(p) with 32 consecutive workers per XCD
+// (32 CUs each): hand-offs between neighbours stay inside one L2.  Progress: block g only waits for blocks that
+// never wait for g, the first block waits for none, and the idle workgroups of the grid exit at once.
+constexpr int TRSV_FLOW_MAX_BLOCKS = 128;
+__device__ __forceinline__ bool trsv_pending(double v) { return __double_as_longlong(v) == -1LL; }
+template <bool TRANSPOSE>
+__global__ __launch_bounds__(256) void k_trsv_flow(const double* __restrict__ L, int n, const double* __restrict__ Dinv,
+                                                   const double* __restrict__ DinvT, const double* __restrict__ b,
+                                                   double* __restrict__ xout) {
+  __shared__ double sM[128 * 128];
+  __shared__ double sacc[128], sx[128], shalf[128];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int nblk = (n + 127) / 128;
+  const int p = (int)blockIdx.x >> 3;                                          // position in the dependency order
+  if (((int)blockIdx.x & 7) != ((p >> 5) & 7)) return;
+  const int g = TRANSPOSE ? nblk - 1 - p : p;
+  const int r0 = g * 128;
+  const int nbg = (n - r0) < 128 ? (n - r0) : 128;
+  {
+    // forward: y[r] = sum_c Dinv[r][c] acc[c] read as DinvT[c][r];  transpose: x[r] = sum_c Dinv[c][r] acc[c]
+    const double* M = (TRANSPOSE ? Dinv : DinvT) + (size_t)g * 128 * 128;
+    for (int e = tid; e < 128 * 128; e += 256) sM[e] = M[e];
+  }
+  if (tid < 128) sacc[tid] = (tid < nbg) ? b[r0 + tid] : 0.0;
+  const int i = tid & 127, h = tid >> 7;
+  double part = 0.0;                       // TRANSPOSE: this thread's half of the column sums, over all blocks
+  __syncthreads();
+  const int first = TRANSPOSE ? nblk - 1 : 0, step = TRANSPOSE ? -1 : 1;
+  // The 128x128 tile of L that couples block `blk` to this block does not depend on any flag: it is loaded into
+  // registers BEFORE waiting for x_blk, so after the hand-off only LDS reads and FMAs remain on the chain.
+  //   TRANSPOSE: lt[c] = L[rb + 64 h + c][r0 + i]          (column i of this block, coalesced over i)
+  //   forward  : lt[2k], lt[2k+1] = L[r0 + w + 4k][rb + lane], [rb + 64 + lane]   (row per wavefront pass)
+  double lt[64];
+  auto load_tile = [&](int blk) {
+    const int rb = blk * 128;
+    const int nbb = (n - rb) < 128 ? (n - rb) : 128;
+    if (TRANSPOSE) {
+      const double* lp = L + (size_t)(rb + h * 64) * n + r0 + i;
+#pragma unroll
+      for (int c = 0; c < 64; ++c) lt[c] = (i < nbg && h * 64 + c < nbb) ? lp[(size_t)c * n] : 0.0;
+    } else {
+#pragma unroll
+      for (int k = 0; k < 32; ++k) {
+        const int q = w + 4 * k;
+        const double* lrow = L + (size_t)(r0 + q) * n + rb;
+        lt[2 * k] = (q < nbg) ? lrow[lane] : 0.0;               // earlier blocks are full
+        lt[2 * k + 1] = (q < nbg) ? lrow[64 + lane] : 0.0;
+      }
+    }
+  };
+  if (first != g) load_tile(first);
+  for (int blk = first; blk != g; blk += step) {
+    const int rb = blk * 128;
+    const int nbb = (n - rb) < 128 ? (n - rb) : 128;
+    __syncthreads();                                 // everyone is done with the previous sx
+    if (tid < 128) {
+      double v = 0.0;
+      if (tid < nbb) {
+        do { v = __hip_atomic_load(&xout[rb + tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); } while (trsv_pending(v));
+      }
+      sx[tid] = v;
+    }
+    __syncthreads();
+    if (TRANSPOSE) {
+#pragma unroll
+      for (int c = 0; c < 64; ++c) part += lt[c] * sx[h * 64 + c];
+    } else {
+      const double x0 = sx[lane], x1 = sx[64 + lane];
+#pragma unroll
+      for (int k = 0; k < 32; ++k) {
+        const double t = wave_sum_d(lt[2 * k] * x0 + lt[2 * k + 1] * x1);
+        if (lane == 0 && w + 4 * k < nbg) sacc[w + 4 * k] -= t;
+      }
+    }
+    if (blk + step != g) load_tile(blk + step);     // in flight while the next flag is awaited
+  }
+  __syncthreads();
+  if (TRANSPOSE) {
+    if (h == 1) shalf[i] = part;
+    __syncthreads();
+    if (h == 0) sacc[i] -= part + shalf[i];
+    __syncthreads();
+  }
+  double s = 0.0;
+#pragma unroll 8
+  for (int c = h * 64; c < h * 64 + 64; ++c) s += sM[c * 128 + i] * sacc[c];
+  if (h == 1) shalf[i] = s;
+  __syncthreads();
+  if (h == 0 && i < nbg) __hip_atomic_store(&xout[r0 + i], s + shalf[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 // ------------------------------------------------------------------------------------ host
 int dense_cholesky(sfm_ctx* h, double* A, int n, int nrows, const DenseWs& w) {
-  hipLaunchKernelGGL(k_chol_diag, dim3(1), dim3(256), 0, h->stream, A, n, w.Ld, w.inv64, w.flag);
-  for (int j0 = 0; j0 < n; j0 += 64) {
+  hipLaunchKernelGGL(k_chol_first, dim3(1), dim3(256), 0, h->stream, A, w.Lm, n, w.Ld, w.inv64, w.flag);
+  int step = 0;
+  for (int j0 = 0; j0 < n; j0 += 64, ++step) {
     const int nb = (n - j0) < 64 ? (n - j0) : 64;
     const int j1 = j0 + nb;
     const int below = nrows - j1;
     if (below <= 0) break;
-    hipLaunchKernelGGL(k_chol_panel, dim3(cdiv(below, 64)), dim3(256), 0, h->stream, A, n, nrows, j0, w.panel, w.Ld);
-    if (j1 < n) {         // trailing columns exist: update them; tile (0,0) factors + inverts the next diagonal block
-      const unsigned T = cdiv(below, 64);
-      hipLaunchKernelGGL(k_chol_update, dim3(T * (T + 1) / 2), dim3(256), 0, h->stream, A, n, nrows, j1, w.panel, w.Ld,
-                         w.inv64 + (size_t)(j1 / 64) * 64 * 64, w.flag);
-    }
+    const unsigned T = cdiv(below, 64);
+    double* D = w.Ld + (size_t)(step & 1) * 64 * 64;
+    double* Dn = w.Ld + (size_t)((step + 1) & 1) * 64 * 64;
+    // tiles of the trailing matrix; with no trailing columns left (j1 == n) only the bordered row is solved
+    hipLaunchKernelGGL(k_chol_step, dim3(j1 < n ? T * (T + 1) / 2 : T), dim3(256), 0, h->stream, A, w.Lm, n, nrows, j0,
+                       D, Dn, w.inv64 + (size_t)(j1 / 64) * 64 * 64, w.flag);
   }
-  // 128x128 diagonal-block inverses for the triangular solves from the 64x64 ones the factorisation left behind
-  const unsigned nb128 = cdiv(n, 128);
-  if ((cdiv(n, 64) & 1u) != 0)      // odd number of 64-blocks: the partner of the last one is an identity block
-    hipLaunchKernelGGL(k_set_identity64, dim3(1), dim3(256), 0, h->stream, w.inv64 + (size_t)cdiv(n, 64) * 64 * 64);
-  hipLaunchKernelGGL(k_inv_merge, dim3(nb128), dim3(256), 0, h->stream, A, n, w.inv64, w.Dinv, w.DinvT);
+  // 64x64 and then 128x128 diagonal-block inverses for the triangular solves
+  const unsigned nb64 = cdiv(n, 64), nb128 = cdiv(n, 128);
+  hipLaunchKernelGGL(k_inv64_fix, dim3(nb64), dim3(256), 0, h->stream, w.Lm, n, w.inv64);
+  if ((nb64 & 1u) != 0)             // odd number of 64-blocks: the partner of the last one is an identity block
+    hipLaunchKernelGGL(k_set_identity64, dim3(1), dim3(256), 0, h->stream, w.inv64 + (size_t)nb64 * 64 * 64);
+  hipLaunchKernelGGL(k_inv_merge, dim3(nb128), dim3(256), 0, h->stream, w.Lm, n, w.inv64, w.Dinv, w.DinvT);
   SFM_LAUNCH_CHECK(h, "dense_cholesky");
   return SFM_OK;
 }
 
-int dense_trsv(sfm_ctx* h, const double* L, int n, const DenseWs& w, double* b, double* xout, int transpose) {
+int dense_trsv(sfm_ctx* h, int n, const DenseWs& w, double* b, double* xout, int transpose) {
+  const double* L = w.Lm;
   const int nblk = (n + 127) / 128;
+  if (nblk <= TRSV_FLOW_MAX_BLOCKS) {
+    if (hipMemsetAsync(xout, 0xFF, (size_t)n * sizeof(double), h->stream) != hipSuccess)     // "not published yet"
+      return sfm_fail(h, SFM_ERR_HIP, "dense_trsv", "memset");
+    if (transpose)
+      hipLaunchKernelGGL(k_trsv_flow<true>, dim3(8 * nblk), dim3(256), 0, h->stream, L, n, w.Dinv, w.DinvT, b, xout);
+    else
+      hipLaunchKernelGGL(k_trsv_flow<false>, dim3(8 * nblk), dim3(256), 0, h->stream, L, n, w.Dinv, w.DinvT, b, xout);
+    SFM_LAUNCH_CHECK(h, "dense_trsv");
+    return SFM_OK;
+  }
   if (!transpose) {
     for (int blk = 0; blk < nblk; ++blk) {
       const int after = n - (blk * 128 + 128);
@@ -575,7 +761,9 @@ extern "C" int sfm_dense_cholesky(sfm_handle h, double* a, int32_t n, int32_t* f
   DenseWs w; dense_ws_carve(base, n, &w);
   w.flag = fail_flag;
   SFM_HIP(h, hipMemsetAsync(fail_flag, 0, sizeof(int), h->stream));
+  SFM_HIP(h, hipMemsetAsync(w.Lm, 0, (size_t)n * n * sizeof(double), h->stream));
   int rc = dense_cholesky(h, a, n, n, w);
+  SFM_HIP(h, hipMemcpyAsync(a, w.Lm, (size_t)n * n * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
   SFM_HIP(h, hipStreamSynchronize(h->stream));
   SFM_HIP(h, hipFree(base));
   return rc;
@@ -587,10 +775,11 @@ extern "C" int sfm_dense_trsv(sfm_handle h, const double* l, int32_t n, double* 
   SFM_HIP(h, hipMalloc(&base, ((size_t)dense_ws_doubles(n) + n) * sizeof(double)));
   DenseWs w; dense_ws_carve(base, n, &w);
   double* xout = base + dense_ws_doubles(n);
+  SFM_HIP(h, hipMemcpyAsync(w.Lm, l, (size_t)n * n * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
   const unsigned nb128 = cdiv(n, 128);
   hipLaunchKernelGGL(k_inv64, dim3(2 * nb128), dim3(64), 0, h->stream, l, n, w.inv64);
   hipLaunchKernelGGL(k_inv_merge, dim3(nb128), dim3(256), 0, h->stream, l, n, w.inv64, w.Dinv, w.DinvT);
-  int rc = dense_trsv(h, l, n, w, b, xout, transpose ? 1 : 0);
+  int rc = dense_trsv(h, n, w, b, xout, transpose ? 1 : 0);
   if (rc == SFM_OK) {
     SFM_HIP(h, hipMemcpyAsync(b, xout, (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
     SFM_HIP(h, hipStreamSynchronize(h->stream));
