@@ -20,6 +20,15 @@
 
 typedef double v4d __attribute__((ext_vector_type(4)));
 
+// Phase timestamps of the serial chain (tools/microbench/chol_phases.hip defines SFM_DENSE_PHASE_TIMING); no-ops
+// in the library build.
+#ifdef SFM_DENSE_PHASE_TIMING
+__device__ unsigned long long g_phase_t[32];
+#define PHASE_T(k) do { if (threadIdx.x == 0 && blockIdx.x == 0) g_phase_t[k] = wall_clock64(); } while (0)
+#else
+#define PHASE_T(k) do { } while (0)
+#endif
+
 __device__ __forceinline__ double readlane_d(double v, int l) {
   int lo = __builtin_amdgcn_readlane(__double2loint(v), l);
   int hi = __builtin_amdgcn_readlane(__double2hiint(v), l);
@@ -119,22 +128,31 @@ __device__ __forceinline__ bool wave_chol32(double (&a)[16], int lane, double* _
 }
 
 // Inverse of the factor being produced by wave_chol32 in ANOTHER wavefront of the same workgroup: lane t
-// (both half-waves alike) forward-substitutes column t; row r only needs columns <= r of L, so this runs one
-// column behind the factorisation instead of after it.  The producer never waits for the consumer, so the
-// spin cannot deadlock.  Result: sLi[r*33 + t] = (L^-1)[r][t].
+// (both half-waves alike) builds column t of L^-1 by forward substitution in OUTER-PRODUCT order: when column j
+// of L is published, x[j] = (e_t[j] - acc[j]) / L[j][j] is final and acc[r] += L[r][j] x[j] (r > j) are
+// independent FMAs, so the consumer is one multiply behind the producer's last column instead of a 31-long
+// dependent chain.  The producer never waits for the consumer, so the spin cannot deadlock.
+// Result: sLi[r*ldl + t] = (L^-1)[r][t].
 __device__ __forceinline__ void wave_inv32_follow(const double* __restrict__ sC, const double* __restrict__ srd,
                                                   int* __restrict__ s_ready, int lane, double* __restrict__ sLi, int ldl) {
-  const int t = lane & 31;
-  double x[32];
+  // lane (t, h): column t of the inverse, rows r = 2u + h of the running sums acc (the two half-waves split the
+  // rows, v_permlane32_swap hands x[j] from the half that owns row j to the other one)
+  const int t = lane & 31, h = lane >> 5;
+  double acc[16];
 #pragma unroll
-  for (int r = 0; r < 32; ++r) {
-    while (__hip_atomic_load(s_ready, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < r + 1) __builtin_amdgcn_s_sleep(1);
+  for (int u = 0; u < 16; ++u) acc[u] = 0.0;
+#pragma unroll
+  for (int j = 0; j < 32; ++j) {
+    const int hj = j & 1, uj = j >> 1;
+    while (__hip_atomic_load(s_ready, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < j + 1) __builtin_amdgcn_s_sleep(1);
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    double s = (r == t) ? 1.0 : 0.0;
+    const double mine = (j >= t) ? (((j == t) ? 1.0 : 0.0) - acc[uj]) * srd[j] : 0.0;     // valid in half hj
+    const double xj = half_bcast(mine, hj);
+    sLi[j * ldl + t] = xj;
+    const double* col = sC + j * 32 + h;
+    if (hj == 0) acc[uj] += (h == 1) ? col[2 * uj] * xj : 0.0;       // row j + 1 = 2 uj + 1 belongs to half 1
 #pragma unroll
-    for (int c = 0; c < r; ++c) s -= sC[c * 32 + r] * x[c];
-    x[r] = (r >= t) ? s * srd[r] : 0.0;
-    sLi[r * ldl + t] = x[r];
+    for (int u = uj + 1; u < 16; ++u) acc[u] += col[2 * u] * xj;
   }
 }
 
@@ -195,6 +213,7 @@ __device__ __forceinline__ void crit64_lite(const Crit64& c, int tid, FL store_L
   const int kq = lane >> 4, r16 = lane & 15;
   if (tid == 0) { c.flag[0] = 0; c.flag[1] = 0; }
   __syncthreads();
+  PHASE_T(8);
   if (w < 2) __builtin_amdgcn_s_setprio(3);     // the serial chain: ahead of the bulk tiles sharing these SIMDs
   // ---- P1: A11 = L11 L11^T (wave 0), Li11 = L11^-1 (wave 1, one column behind)
   if (w == 0) {
@@ -202,10 +221,12 @@ __device__ __forceinline__ void crit64_lite(const Crit64& c, int tid, FL store_L
 #pragma unroll
     for (int t = 0; t < 16; ++t) { const int q = 2 * t + h; a[t] = (q <= i) ? c.sM[i * LDM + q] : 0.0; }
     if (!wave_chol32(a, lane, c.sC, c.srd, &c.flag[0]) && lane == 0) *fail = 1;
+    PHASE_T(9);
   } else if (w == 1) {
     wave_inv32_follow(c.sC, c.srd, &c.flag[0], lane, c.sLi11, LDL);
   }
   __syncthreads();
+  PHASE_T(10);
   // ---- P2: L21 = A21 Li11^T
   {
     const v4d acc = mm32_tile<true>(c.sM + 32 * LDM, LDM, c.sLi11, LDL, tr, tc, lane);
@@ -219,6 +240,7 @@ __device__ __forceinline__ void crit64_lite(const Crit64& c, int tid, FL store_L
     if (cc <= r) { store_L(r, cc, c.sC[cc * 32 + r]); store_Li(r, cc, c.sLi11[r * LDL + cc]); }
   }
   __syncthreads();
+  PHASE_T(11);
   // ---- P3: A22 -= L21 L21^T
   {
     const v4d u = mm32_tile<true>(c.sM + 32 * LDM, LDM, c.sM + 32 * LDM, LDM, tr, tc, lane);
@@ -226,6 +248,7 @@ __device__ __forceinline__ void crit64_lite(const Crit64& c, int tid, FL store_L
     for (int q = 0; q < 4; ++q) c.sM[(32 + tr * 16 + kq + 4 * q) * LDM + 32 + tc * 16 + r16] -= u[q];
   }
   __syncthreads();
+  PHASE_T(12);
   // ---- P4: A22 = L22 L22^T, Li22
   if (w == 0) {
     double a[16];
@@ -236,6 +259,7 @@ __device__ __forceinline__ void crit64_lite(const Crit64& c, int tid, FL store_L
     wave_inv32_follow(c.sC, c.srd + 32, &c.flag[1], lane, c.sLi22, LDL);
   }
   __syncthreads();
+  PHASE_T(13);
   for (int e = tid; e < 32 * 32; e += 256) {
     const int r = e >> 5, cc = e & 31;
     const double l21 = c.sM[(32 + r) * LDM + cc];
@@ -243,29 +267,32 @@ __device__ __forceinline__ void crit64_lite(const Crit64& c, int tid, FL store_L
     store_L21(32 + r, cc, l21);
     if (cc <= r) { store_L(32 + r, 32 + cc, c.sC[cc * 32 + r]); store_Li(32 + r, 32 + cc, c.sLi22[r * LDL + cc]); }
   }
+  PHASE_T(14);
 }
 
 // Step data of one diagonal block as the step kernel reads it: D [64][64] row-major =
 // [Li11 0; L21 Li22] (32x32 quadrants; identity-padded when the block is short).
 // Factor the first 64x64 diagonal block: L -> Lm, step data -> D, diagonal 32-block inverses -> inv64.
-__global__ __launch_bounds__(256) void k_chol_first(const double* __restrict__ A, double* __restrict__ Lm, int n,
-                                                    double* __restrict__ D, double* __restrict__ inv64,
-                                                    int* __restrict__ fail) {
-  __shared__ double smem[CRIT64_DOUBLES + 6];     // static: with `extern __shared__` hipcc needs 256 + 68 registers here
+__device__ __forceinline__ void chol_first_block(double* smem, const double* __restrict__ A, double* __restrict__ Lm, int n,
+                                                 double* __restrict__ D, double* __restrict__ inv64, int* __restrict__ fail) {
   const Crit64 c = crit64_carve(smem);
   const int tid = threadIdx.x;
   const int nb = n < 64 ? n : 64;
   for (int e = tid; e < 64 * 64; e += 256) {
     const int r = e >> 6, cc = e & 63;
     c.sM[r * LDM + cc] = (r < nb && cc < nb) ? ((cc <= r) ? A[(size_t)r * n + cc] : 0.0) : ((r == cc) ? 1.0 : 0.0);
-    D[e] = 0.0;
-    inv64[e] = 0.0;
   }
   __syncthreads();
   crit64_lite(c, tid,
               [&](int r, int cc, double v) { if (r < nb && cc < nb) Lm[(size_t)r * n + cc] = v; },
               [&](int r, int cc, double v) { D[r * 64 + cc] = v; inv64[r * 64 + cc] = v; },
               [&](int r, int cc, double v) { D[r * 64 + cc] = v; }, fail);
+}
+__global__ __launch_bounds__(256) void k_chol_first(const double* __restrict__ A, double* __restrict__ Lm, int n,
+                                                    double* __restrict__ D, double* __restrict__ inv64,
+                                                    int* __restrict__ fail) {
+  __shared__ double smem[CRIT64_DOUBLES + 6];     // static: with `extern __shared__` hipcc needs 256 + 68 registers here
+  chol_first_block(smem, A, Lm, n, D, inv64, fail);
 }
 
 // X = A_rows L_jj^-T for the 16 rows [row, row + 16) of this wavefront, 64 columns, in two 32-wide stages on
@@ -274,24 +301,31 @@ __global__ __launch_bounds__(256) void k_chol_first(const double* __restrict__ A
 // result layout has to become an A-operand layout between the stages, which is a round trip through dst) and
 // in x[4] (C layout: row = kq + 4 i, column = 16 t + r16).  All four wavefronts call this together
 // (__syncthreads inside).  Rows >= nrows and columns >= nb read as zero.
-__device__ __forceinline__ void trsm_rows16(const double* __restrict__ A, int n, int nrows, int j0, int nb, int row,
-                                            const double* __restrict__ sD, double* __restrict__ dst, int lane,
-                                            v4d (&x)[4]) {
+struct TrsmIn {
+  double a1[8];        // A1 as MFMA A operand: row r16, k = 4 s + kq
+  double a2c[2][4];    // A2 in the result layout: row kq + 4 i, column 32 + 16 t + r16
+};
+// the global loads of trsm_rows16, separate so that they are in flight together with the step-data staging
+__device__ __forceinline__ void trsm_load(const double* A, int n, int nrows, int j0, int nb, int row, int lane, TrsmIn& in) {
   const int r16 = lane & 15, kq = lane >> 4;
   const int arow = row + r16;
   const bool aok = arow < nrows;
   const double* ap = A + (size_t)arow * n + j0;
-  double a1[8];
 #pragma unroll
-  for (int s4 = 0; s4 < 8; ++s4) a1[s4] = (aok && (4 * s4 + kq) < nb) ? ap[4 * s4 + kq] : 0.0;
-  double a2c[2][4];                               // A2 in the result layout
+  for (int s4 = 0; s4 < 8; ++s4) in.a1[s4] = (aok && (4 * s4 + kq) < nb) ? ap[4 * s4 + kq] : 0.0;
 #pragma unroll
   for (int t = 0; t < 2; ++t)
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int gr = row + kq + 4 * i, col = 32 + 16 * t + r16;
-      a2c[t][i] = (gr < nrows && col < nb) ? A[(size_t)gr * n + j0 + col] : 0.0;
+      in.a2c[t][i] = (gr < nrows && col < nb) ? A[(size_t)gr * n + j0 + col] : 0.0;
     }
+}
+__device__ __forceinline__ void trsm_rows16(const TrsmIn& in, const double* __restrict__ sD, double* __restrict__ dst,
+                                            int lane, v4d (&x)[4]) {
+  const int r16 = lane & 15, kq = lane >> 4;
+  const double (&a1)[8] = in.a1;
+  const double (&a2c)[2][4] = in.a2c;
 #pragma unroll
   for (int t = 0; t < 4; ++t) x[t] = (v4d){0.0, 0.0, 0.0, 0.0};
   // stage 1: Li11 is lower triangular, column tile t only has k <= 16 t + 15
@@ -348,19 +382,20 @@ __device__ __forceinline__ void trsm_rows16(const double* __restrict__ A, int n,
 //   4. LOOK-AHEAD: the workgroup of tile (0,0) then factors the next diagonal block in LDS (crit64_lite) and
 //      publishes its step data to Dn for the next launch, so the serial chain never waits for a kernel of its own.
 // A's panel columns are only read here (never overwritten), which is what makes step 1 race-free.
-__global__ __launch_bounds__(256) void k_chol_step(double* __restrict__ A, double* __restrict__ Lm, int n, int nrows,
-                                                   int j0, const double* __restrict__ D, double* __restrict__ Dn,
-                                                   double* __restrict__ inv64_next, int* __restrict__ fail) {
-  __shared__ double smem[CRIT64_DOUBLES + 6 + 64 * LDM];     // 102.5 KB static (gfx950 allows up to 160 KB)
+constexpr int CHOL_STEP_SMEM = CRIT64_DOUBLES + 6 + 64 * LDM;     // 102.5 KB static (gfx950 allows up to 160 KB)
+// tile b of the step at panel j0 (see k_chol_step); all 256 threads of the workgroup, smem = CHOL_STEP_SMEM doubles
+__device__ __forceinline__ void chol_tile(double* smem, int b, bool stage_d, double* A, double* __restrict__ Lm, int n,
+                                          int nrows, int j0, const double* D, double* Dn, double* inv64_next,
+                                          int* __restrict__ fail) {
   double* sI = smem;                 // [64][LDM]
   double* sJ = smem + 64 * LDM;      // [64][LDM]   (the factor's buffers later reuse sI/sJ)
   double* sD = smem + CRIT64_DOUBLES + 6;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-  // 1-D grid over the lower-triangular tiles only: block b -> (ti, tj), tj <= ti, b = ti (ti + 1) / 2 + tj
-  int ti = (int)((sqrtf(8.0f * (float)blockIdx.x + 1.0f) - 1.0f) * 0.5f);
-  while ((ti + 1) * (ti + 2) / 2 <= (int)blockIdx.x) ++ti;
-  while (ti * (ti + 1) / 2 > (int)blockIdx.x) --ti;
-  const int tj = (int)blockIdx.x - ti * (ti + 1) / 2;
+  // 1-D order over the lower-triangular tiles only: b -> (ti, tj), tj <= ti, b = ti (ti + 1) / 2 + tj
+  int ti = (int)((sqrtf(8.0f * (float)b + 1.0f) - 1.0f) * 0.5f);
+  while ((ti + 1) * (ti + 2) / 2 <= b) ++ti;
+  while (ti * (ti + 1) / 2 > b) --ti;
+  const int tj = b - ti * (ti + 1) / 2;
   const int nb = (n - j0) < 64 ? (n - j0) : 64;
   const int j1 = j0 + nb;
   const int rem_r = nrows - j1, rem_c = n - j1;
@@ -375,10 +410,16 @@ __global__ __launch_bounds__(256) void k_chol_step(double* __restrict__ A, doubl
       const int gr = I0 + w * 16 + rq + 4 * i, gcol = J0 + t * 16 + col16;
       cv[t][i] = (gr < rem_r && gcol < rem_c && gcol <= gr) ? A[(size_t)(j1 + gr) * n + j1 + gcol] : 0.0;
     }
-  for (int e = tid; e < 64 * 64; e += 256) sD[(e >> 6) * LDM + (e & 63)] = D[e];
+  PHASE_T(0);
+  TrsmIn inI, inJ;
+  trsm_load(A, n, nrows, j0, nb, j1 + I0 + w * 16, lane, inI);
+  if (ti != tj && rem_c > 0) trsm_load(A, n, nrows, j0, nb, j1 + J0 + w * 16, lane, inJ);
+  if (stage_d)
+    for (int e = tid; e < 64 * 64; e += 256) sD[(e >> 6) * LDM + (e & 63)] = D[e];
   __syncthreads();
+  PHASE_T(1);
   v4d xi[4], xj[4];
-  trsm_rows16(A, n, nrows, j0, nb, j1 + I0 + w * 16, sD, sI + w * 16 * LDM, lane, xi);
+  trsm_rows16(inI, sD, sI + w * 16 * LDM, lane, xi);
   if (tj == 0) {
 #pragma unroll
     for (int t = 0; t < 4; ++t)
@@ -388,10 +429,11 @@ __global__ __launch_bounds__(256) void k_chol_step(double* __restrict__ A, doubl
         if (gr < nrows && col < nb) Lm[(size_t)gr * n + j0 + col] = xi[t][i];
       }
   }
+  PHASE_T(2);
   if (rem_c <= 0) return;                          // only the bordered row was left: nothing to update
   const double* sJr = sI;
   if (ti != tj) {
-    trsm_rows16(A, n, nrows, j0, nb, j1 + J0 + w * 16, sD, sJ + w * 16 * LDM, lane, xj);
+    trsm_rows16(inJ, sD, sJ + w * 16 * LDM, lane, xj);
     sJr = sJ;
   }
   v4d acc[4];
@@ -406,6 +448,7 @@ __global__ __launch_bounds__(256) void k_chol_step(double* __restrict__ A, doubl
       acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[t], 0, 0, 0);
     }
   }
+  PHASE_T(3);
   const bool crit = (ti == 0 && tj == 0);
   const int nbn = rem_c < 64 ? rem_c : 64;        // size of the next diagonal block (rem_c >= 1 here)
   if (crit) __syncthreads();                       // the tiles are about to become the factor's buffers
@@ -424,18 +467,26 @@ __global__ __launch_bounds__(256) void k_chol_step(double* __restrict__ A, doubl
       else if (inside) A[(size_t)(j1 + gr) * n + j1 + gcol] = v;
     }
   if (!crit) return;
-  // identity outside the valid corner; clear what the stores below do not touch
-  for (int e = tid; e < 64 * 64; e += 256) {
-    const int r = e >> 6, cc = e & 63;
-    if (r >= nbn || cc >= nbn) c.sM[r * LDM + cc] = (r == cc) ? 1.0 : 0.0;
-    Dn[e] = 0.0;
-    inv64_next[e] = 0.0;
+  // identity outside the valid corner (Dn / inv64_next: every launch writes the same positions - the lower
+  // triangles of the two 32x32 inverses and L21 - and dense_cholesky cleared the rest once)
+  if (nbn < 64) {
+    for (int e = tid; e < 64 * 64; e += 256) {
+      const int r = e >> 6, cc = e & 63;
+      if (r >= nbn || cc >= nbn) c.sM[r * LDM + cc] = (r == cc) ? 1.0 : 0.0;
+    }
   }
   __syncthreads();
   crit64_lite(c, tid,
               [&](int r, int cc, double v) { if (r < nbn && cc < nbn) Lm[(size_t)(j1 + r) * n + j1 + cc] = v; },
               [&](int r, int cc, double v) { Dn[r * 64 + cc] = v; inv64_next[r * 64 + cc] = v; },
               [&](int r, int cc, double v) { Dn[r * 64 + cc] = v; }, fail);
+}
+
+__global__ __launch_bounds__(256) void k_chol_step(double* A, double* __restrict__ Lm, int n, int nrows, int j0,
+                                                   const double* D, double* Dn, double* inv64_next,
+                                                   int* __restrict__ fail) {
+  __shared__ double smem[CHOL_STEP_SMEM];
+  chol_tile(smem, (int)blockIdx.x, true, A, Lm, n, nrows, j0, D, Dn, inv64_next, fail);
 }
 
 // Off-diagonal quadrant of each 64x64 diagonal-block inverse, for the triangular solves:
@@ -699,6 +750,10 @@ __global__ __launch_bounds__(256) void k_trsv_flow(const double* __restrict__ L,
 
 // ------------------------------------------------------------------------------------ host
 int dense_cholesky(sfm_ctx* h, double* A, int n, int nrows, const DenseWs& w) {
+  // step data and block inverses: the kernels only write their structural non-zeros
+  if (hipMemsetAsync(w.Ld, 0, (size_t)2 * 64 * 64 * sizeof(double), h->stream) != hipSuccess ||
+      hipMemsetAsync(w.inv64, 0, (size_t)((n + 127) / 128) * 2 * 64 * 64 * sizeof(double), h->stream) != hipSuccess)
+    return sfm_fail(h, SFM_ERR_HIP, "dense_cholesky", "memset");
   hipLaunchKernelGGL(k_chol_first, dim3(1), dim3(256), 0, h->stream, A, w.Lm, n, w.Ld, w.inv64, w.flag);
   int step = 0;
   for (int j0 = 0; j0 < n; j0 += 64, ++step) {
