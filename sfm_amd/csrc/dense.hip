@@ -682,13 +682,14 @@ __global__ __launch_bounds__(256) void k_trsv_flow(const double* __restrict__ L,
   }
   if (tid < 128) sacc[tid] = (tid < nbg) ? b[r0 + tid] : 0.0;
   const int i = tid & 127, h = tid >> 7;
-  double part = 0.0;                       // TRANSPOSE: this thread's half of the column sums, over all blocks
+  double part = 0.0;                       // this thread's half of row/column i's sum, over all blocks
   __syncthreads();
   const int first = TRANSPOSE ? nblk - 1 : 0, step = TRANSPOSE ? -1 : 1;
   // The 128x128 tile of L that couples block `blk` to this block does not depend on any flag: it is loaded into
   // registers BEFORE waiting for x_blk, so after the hand-off only LDS reads and FMAs remain on the chain.
-  //   TRANSPOSE: lt[c] = L[rb + 64 h + c][r0 + i]          (column i of this block, coalesced over i)
-  //   forward  : lt[2k], lt[2k+1] = L[r0 + w + 4k][rb + lane], [rb + 64 + lane]   (row per wavefront pass)
+  //   TRANSPOSE: lt[c] = L[rb + 64 h + c][r0 + i]      (column i of this block: coalesced over i)
+  //   forward  : lt[c] = L[r0 + i][rb + 64 h + c]      (row i of this block: 512 contiguous bytes per thread;
+  //              uncoalesced, but these loads are issued ahead of the hand-off and are off the chain)
   double lt[64];
   auto load_tile = [&](int blk) {
     const int rb = blk * 128;
@@ -698,13 +699,9 @@ __global__ __launch_bounds__(256) void k_trsv_flow(const double* __restrict__ L,
 #pragma unroll
       for (int c = 0; c < 64; ++c) lt[c] = (i < nbg && h * 64 + c < nbb) ? lp[(size_t)c * n] : 0.0;
     } else {
+      const double* lp = L + (size_t)(r0 + i) * n + rb + h * 64;              // earlier blocks are full
 #pragma unroll
-      for (int k = 0; k < 32; ++k) {
-        const int q = w + 4 * k;
-        const double* lrow = L + (size_t)(r0 + q) * n + rb;
-        lt[2 * k] = (q < nbg) ? lrow[lane] : 0.0;               // earlier blocks are full
-        lt[2 * k + 1] = (q < nbg) ? lrow[64 + lane] : 0.0;
-      }
+      for (int c = 0; c < 64; ++c) lt[c] = (i < nbg) ? lp[c] : 0.0;
     }
   };
   if (first != g) load_tile(first);
@@ -720,26 +717,15 @@ __global__ __launch_bounds__(256) void k_trsv_flow(const double* __restrict__ L,
       sx[tid] = v;
     }
     __syncthreads();
-    if (TRANSPOSE) {
 #pragma unroll
-      for (int c = 0; c < 64; ++c) part += lt[c] * sx[h * 64 + c];
-    } else {
-      const double x0 = sx[lane], x1 = sx[64 + lane];
-#pragma unroll
-      for (int k = 0; k < 32; ++k) {
-        const double t = wave_sum_d(lt[2 * k] * x0 + lt[2 * k + 1] * x1);
-        if (lane == 0 && w + 4 * k < nbg) sacc[w + 4 * k] -= t;
-      }
-    }
+    for (int c = 0; c < 64; ++c) part += lt[c] * sx[h * 64 + c];
     if (blk + step != g) load_tile(blk + step);     // in flight while the next flag is awaited
   }
   __syncthreads();
-  if (TRANSPOSE) {
-    if (h == 1) shalf[i] = part;
-    __syncthreads();
-    if (h == 0) sacc[i] -= part + shalf[i];
-    __syncthreads();
-  }
+  if (h == 1) shalf[i] = part;
+  __syncthreads();
+  if (h == 0) sacc[i] -= part + shalf[i];
+  __syncthreads();
   double s = 0.0;
 #pragma unroll 8
   for (int c = h * 64; c < h * 64 + 64; ++c) s += sM[c * 128 + i] * sacc[c];
