@@ -1,21 +1,22 @@
 // Dense SPD solver for the reduced camera system (n = n_cams * cam_dim, a few thousand): bordered
 // lower Cholesky + triangular solves, fp64, gfx950.
 //
-// The factorisation is latency-bound (n/32 dependent panel steps), so the design minimises the work
-// on that chain and the number of kernel boundaries:
+// The factorisation is latency-bound (n/64 dependent steps), so the design minimises the work on that chain and
+// the number of kernel boundaries (phase timings: tools/microbench/chol_phases.hip):
 //   wave_chol32    : 32x32 diagonal block in ONE wavefront (lane = row, columns split over the two
 //                    half-waves, finished column broadcast through LDS, 1/sqrt by v_rsq_f64 + two Newton
 //                    steps instead of sqrt + divide)
-//   wave_inv32_follow : its inverse on a SECOND wavefront of the same workgroup, one column behind the
-//                    factor (producer/consumer through LDS), so it adds almost nothing to the chain
-//   k_chol_panel   : rows below the block as a 32-deep MFMA product with L_jj^-1
-//   k_chol_update  : rank-32 update of the trailing lower tiles on v_mfma_f64_16x16x4_f64, panel rows
-//                    staged in LDS (row stride 34 doubles = conflict-free ds_read_b64); LOOK-AHEAD: the
-//                    workgroup of tile (0,0) factors the next diagonal block right after updating it, so
-//                    the serial chain has no kernel of its own                -> 2 launches per step
-//   k_inv64 / k_inv_merge : explicit inverses of the 128x128 diagonal blocks of L (both layouts), so
-//   k_trsv_step    : one launch per 128-row block: every workgroup recomputes x_blk = Dinv * rhs_blk
-//                    (coalesced 128-long dot products) and updates its own rows of the right-hand side.
+//   wave_inv32_follow : its inverse on a SECOND wavefront of the same workgroup, in outer-product order one
+//                    column behind the factor (producer/consumer through LDS): +0.6 us on the chain
+//   crit64_lite    : a 64x64 diagonal block = two of those + two 32^3 MFMA products; only the two 32x32
+//                    inverses are formed on the chain
+//   k_chol_step    : ONE launch per 64-column step: every trailing tile re-solves its own panel rows against
+//                    the step data [Li11 0; L21 Li22] (trsm_rows16, MFMA), applies the rank-64 update, and the
+//                    workgroup of tile (0,0) factors the next diagonal block right away (LOOK-AHEAD).  The
+//                    factor is written to a separate matrix Lm; the panel columns of A stay read-only.
+//   k_inv64_fix / k_inv_merge : explicit inverses of the 128x128 diagonal blocks of L (both layouts), so that
+//   k_trsv_flow    : a whole triangular solve is one launch of n/128 workgroups handing their 128 unknowns
+//                    on through the output vector itself (k_trsv_step: one launch per block, for n > 16384).
 #include "dense.h"
 
 typedef double v4d __attribute__((ext_vector_type(4)));
