@@ -18,6 +18,7 @@
 //   k_trsv_flow    : a whole triangular solve is one launch of n/128 workgroups handing their 128 unknowns
 //                    on through the output vector itself (k_trsv_step: one launch per block, for n > 16384).
 #include "dense.h"
+#include <cstdlib>
 
 typedef double v4d __attribute__((ext_vector_type(4)));
 
@@ -713,7 +714,11 @@ __global__ __launch_bounds__(256) void k_trsv_flow(const double* __restrict__ L,
     if (tid < 128) {
       double v = 0.0;
       if (tid < nbb) {
-        do { v = __hip_atomic_load(&xout[rb + tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); } while (trsv_pending(v));
+        // bounded: a producer that never publishes (it cannot, by construction) must not hang the device -
+        // after ~4 s the element is taken as it is (an all-ones NaN) and the caller sees a non-finite solution
+        int spins = 0;
+        do { v = __hip_atomic_load(&xout[rb + tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+        while (trsv_pending(v) && ++spins < (1 << 22));
       }
       sx[tid] = v;
     }
@@ -768,7 +773,8 @@ int dense_cholesky(sfm_ctx* h, double* A, int n, int nrows, const DenseWs& w) {
 int dense_trsv(sfm_ctx* h, int n, const DenseWs& w, double* b, double* xout, int transpose) {
   const double* L = w.Lm;
   const int nblk = (n + 127) / 128;
-  if (nblk <= TRSV_FLOW_MAX_BLOCKS) {
+  const char* flow = getenv("SFM_TRSV_FLOW");       // "0": one launch per block (the path taken for n > 16384)
+  if (nblk <= TRSV_FLOW_MAX_BLOCKS && !(flow && flow[0] == '0')) {
     if (hipMemsetAsync(xout, 0xFF, (size_t)n * sizeof(double), h->stream) != hipSuccess)     // "not published yet"
       return sfm_fail(h, SFM_ERR_HIP, "dense_trsv", "memset");
     if (transpose)
