@@ -42,6 +42,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-matcher", action="store_true")
     ap.add_argument("--no-d6", action="store_true")
+    ap.add_argument("--no-driver-rows", action="store_true")
     return ap.parse_args()
 
 
@@ -208,6 +209,21 @@ def main():
                    "ms_per_pair_of_images": tm / args.match_reps * 1e3, "n_matches": int(mq.shape[0]),
                    "dtype": "u8/i32", "roofline": mroof}
 
+    # ------------------------------------------------------------------ driver-row kernels, N = 1 only
+    driver_rows = None
+    if rank == 0 and world == 1 and not args.no_driver_rows:
+        try:
+            sys.path.insert(0, os.path.join(ROOT, "tools"))
+            import bench_driver
+            cpu_fns = None
+            if not args.no_cpu_baseline:          # cpu_baseline leg: the NumPy oracle on a bounded sample
+                from oracle import driver_oracle as dro
+                cpu_fns = {"associate": dro.associate, "triangulate_point": dro.triangulate_point,
+                           "symmetric_epipolar_errors": dro.symmetric_epipolar_errors}
+            driver_rows = bench_driver.measure(reps=10, cpu_fns=cpu_fns)
+        except Exception as e:       # secondary figures; never fail the main measurement on them
+            driver_rows = {"error": repr(e)}
+
     # ------------------------------------------------------------------ CPU baseline (rank 0, N = 1 only)
     cpu_baseline = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -233,6 +249,7 @@ def main():
             "ba": {"damped_solves": n_solves, "trial_steps": n_trials, "cost_start": cost0, "cost_end": st.cost,
                    "solves_per_s": n_solves / elapsed, "kernels": kernels},
             "ba_cam_dim6": ba_d6, "roofline": roofline, "cpu_baseline": cpu_baseline, "matcher": matcher,
+            "driver_rows": driver_rows,
         }
         print(json.dumps(out), flush=True)
     if use_dist:

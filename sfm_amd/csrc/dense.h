@@ -3,15 +3,11 @@
 #include "common.h"
 
 struct DenseWs {
-  double* panel;   // [(n+1)][64] current panel
   double* Ld;      // 2 x [64][64] step data of the current / next diagonal block: [Li11 0; L21 Li22] (32x32 quadrants)
-  double* rd;      // unused spare
   double* Dinv;    // [ceil(n/128)][128][128] inverses of the diagonal blocks of L, row-major
   double* DinvT;   // same, transposed
-  double* inv64;   // [2*ceil(n/128)][64][64]
-  double* tmp;     // [ceil(n/128)][64][64]
+  double* inv64;   // [2*ceil(n/128)][64][64] inverses of the 64x64 diagonal blocks
   int* flag;       // set to 1 when a pivot is not positive
-  int* tflag;      // [ceil(n/128)] per-block "solution published" flags of the single-launch triangular solve
   double* Lm;      // [(n+1)][n] the factor (lower part; row n = L^-1 rhs when the input carried a bordered row)
 };
 

@@ -51,21 +51,16 @@ __device__ __forceinline__ double wave_sum_d(double v) {
 
 int64_t dense_ws_doubles(int n) {
   const int64_t nb = (n + 127) / 128;
-  return align_up((int64_t)(n + 1) * 64, 32) + 2 * 64 * 64 + 32 + 2 * nb * 128 * 128 + nb * 2 * 64 * 64 + nb * 64 * 64 + 32 +
-         align_up(nb, 64) + align_up((int64_t)(n + 1) * n, 32);
+  return 2 * 64 * 64 + 2 * nb * 128 * 128 + nb * 2 * 64 * 64 + 32 + align_up((int64_t)(n + 1) * n, 32);
 }
 void dense_ws_carve(double* base, int n, DenseWs* w) {
   const int64_t nb = (n + 127) / 128;
   double* p = base;
-  w->panel = p; p += align_up((int64_t)(n + 1) * 64, 32);
   w->Ld = p; p += 2 * 64 * 64;
-  w->rd = p; p += 32;
   w->Dinv = p; p += nb * 128 * 128;
   w->DinvT = p; p += nb * 128 * 128;
   w->inv64 = p; p += nb * 2 * 64 * 64;
-  w->tmp = p; p += nb * 64 * 64;
   w->flag = (int*)p; p += 32;
-  w->tflag = (int*)p; p += align_up(nb, 64);
   w->Lm = p;
 }
 

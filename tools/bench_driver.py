@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Device-time measurement of the driver-row kernels with inputs resident in HBM:
-association (pair tests/s), two-view triangulation (tracks/s), epipolar verification (matches/s), each
-beside the NumPy oracle timed on a bounded sample.  Prints one JSON line per kernel.
+association (pair tests/s), two-view triangulation (tracks/s), epipolar verification (matches/s).  Prints one
+JSON line per kernel.  bench.py calls measure() and, in its cpu_baseline leg, hands in the NumPy oracle's
+functions to time on a bounded sample of the same inputs (this tool itself never imports oracle/).
 usage: python tools/bench_driver.py [--reps 20]"""
 import argparse
 import ctypes as C
@@ -27,16 +28,22 @@ def timed(fn, reps):
     return s.elapsed_time(e) / reps * 1e-3
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--reps", type=int, default=20)
-    ap.add_argument("--tracks", type=int, default=100000)
-    ap.add_argument("--corr", type=int, default=20000)
-    a = ap.parse_args()
+def measure(reps=20, tracks=100000, corr=20000, cpu_fns=None, emit=None):
+    """[assoc, triangulate, epipolar] result dicts; `emit(dict)` is called as each becomes available.
+    cpu_fns: optional {"associate", "triangulate_point", "symmetric_epipolar_errors"} callables (the oracle's)
+    timed on a bounded sample beside each kernel."""
+    import types
+    a = types.SimpleNamespace(reps=reps, tracks=tracks, corr=corr)
+    results = []
+
+    def out(d):
+        results.append(d)
+        if emit:
+            emit(d)
     import torch
     from sfm_amd import _lib
     from sfm_amd.driver import _p
-    from oracle import driver_oracle as do
+    cpu = cpu_fns is not None
     h = _lib.get_handle(0)
     dev = torch.device("cuda", 0)
     rng = np.random.default_rng(0)
@@ -61,11 +68,13 @@ def main():
                cap, _p(tot), _p(ws), need.value)
     sec = timed(assoc, a.reps)
     ns = min(T, 2000)
-    t0 = time.perf_counter(); do.associate(t[:ns].astype(np.float64), c); cpu = time.perf_counter() - t0
-    print(json.dumps({"kernel": "assoc_radius", "tracks": T, "correspondences": M, "hits": int(tot.item()),
-                      "ms": sec * 1e3, "pair_tests_per_s": T * M / sec,
-                      "fp64_flop_per_s": 5.0 * 2 * T * M / sec,      # 2 passes (count, fill) x 5 flop per test
-                      "cpu_numpy_pair_tests_per_s": ns * M / cpu, "cpu_sample": f"{ns} x {M}"}))
+    r = {"kernel": "assoc_radius", "tracks": T, "correspondences": M, "hits": int(tot.item()),
+         "ms": sec * 1e3, "pair_tests_per_s": T * M / sec,
+         "fp64_flop_per_s": 5.0 * 2 * T * M / sec}      # 2 passes (count, fill) x 5 flop per test
+    if cpu:
+        t0 = time.perf_counter(); cpu_fns["associate"](t[:ns].astype(np.float64), c); sec_cpu = time.perf_counter() - t0
+        r.update(cpu_numpy_pair_tests_per_s=ns * M / sec_cpu, cpu_sample=f"{ns} x {M}")
+    out(r)
 
     # ---- triangulation: n two-view tracks over 64 cameras
     n = 1_000_000
@@ -86,13 +95,15 @@ def main():
                C.c_double(4.0), _p(X), _p(valid), vp(0))
     sec = timed(tri, a.reps)
     ns = 2000
-    t0 = time.perf_counter()
-    for i in range(ns):
-        do.triangulate_point([proj[c0[i]], proj[c1[i]]], [x0[i], x1[i]])
-    cpu = time.perf_counter() - t0
-    print(json.dumps({"kernel": "triangulate2", "tracks": n, "valid_frac": float(valid.float().mean().item()),
-                      "ms": sec * 1e3, "tracks_per_s": n / sec, "hbm_GBps_algorithmic": n * 68 / sec / 1e9,
-                      "cpu_numpy_tracks_per_s": ns / cpu, "cpu_sample": f"{ns} tracks"}))
+    r = {"kernel": "triangulate2", "tracks": n, "valid_frac": float(valid.float().mean().item()),
+         "ms": sec * 1e3, "tracks_per_s": n / sec, "hbm_GBps_algorithmic": n * 68 / sec / 1e9}
+    if cpu:
+        t0 = time.perf_counter()
+        for i in range(ns):
+            cpu_fns["triangulate_point"]([proj[c0[i]], proj[c1[i]]], [x0[i], x1[i]])
+        sec_cpu = time.perf_counter() - t0
+        r.update(cpu_numpy_tracks_per_s=ns / sec_cpu, cpu_sample=f"{ns} tracks")
+    out(r)
 
     # ---- epipolar verification: n matches in 1,000 pairs
     n, n_seg = 10_000_000, 1000
@@ -106,11 +117,24 @@ def main():
         h.call("sfm_epipolar_errors", _p(dF), _p(seg), n_seg, _p(d1), _p(d2), n, C.c_float(3.0), _p(err), _p(mask))
     sec = timed(epi, a.reps)
     ns = 1_000_000
-    t0 = time.perf_counter(); do.symmetric_epipolar_errors(p1[:ns], p2[:ns], F[0].reshape(3, 3)); cpu = time.perf_counter() - t0
-    print(json.dumps({"kernel": "epipolar_errors", "matches": n, "pairs": n_seg, "ms": sec * 1e3,
-                      "matches_per_s": n / sec, "hbm_GBps_algorithmic": n * 21 / sec / 1e9,
-                      "hbm_frac_of_8TBps": n * 21 / sec / 8e12,
-                      "cpu_numpy_matches_per_s": ns / cpu, "cpu_sample": f"{ns} matches"}))
+    r = {"kernel": "epipolar_errors", "matches": n, "pairs": n_seg, "ms": sec * 1e3,
+         "matches_per_s": n / sec, "hbm_GBps_algorithmic": n * 21 / sec / 1e9,
+         "hbm_frac_of_8TBps": n * 21 / sec / 8e12}
+    if cpu:
+        t0 = time.perf_counter(); cpu_fns["symmetric_epipolar_errors"](p1[:ns], p2[:ns], F[0].reshape(3, 3))
+        sec_cpu = time.perf_counter() - t0
+        r.update(cpu_numpy_matches_per_s=ns / sec_cpu, cpu_sample=f"{ns} matches")
+    out(r)
+    return results
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--reps", type=int, default=20)
+    ap.add_argument("--tracks", type=int, default=100000)
+    ap.add_argument("--corr", type=int, default=20000)
+    a = ap.parse_args()
+    measure(a.reps, a.tracks, a.corr, emit=lambda d: print(json.dumps(d), flush=True))
 
 
 if __name__ == "__main__":
