@@ -26,6 +26,7 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s (6.29 TB/s measured copy)
 I8_MFMA_PEAK_TOPS = 5000.0   # dense i8 MFMA = 2x bf16 (~2.5 PF)
+FP64_MFMA_PEAK_TFLOPS = 78.6 # v_mfma_f64_16x16x4_f64: 64 cycles per issue measured = 32 FLOP/clk/SIMD x 1024 SIMDs x 2.4 GHz
 
 
 def parse():
@@ -150,6 +151,20 @@ def main():
             pass
     kernels = {k: {"ms_total": round(v[0], 3), "launches": v[1],
                    "share": round(v[0] / (elapsed * 1e3), 4)} for k, v in prof.items() if v[1] > 0}
+    # the two kernels that dominate the TIME are not HBM- or MFMA-bound; their rates are
+    # reported for completeness: the Schur gather in bytes of G blocks it pulls through L2/MALL, the Cholesky
+    # in fp64 FLOP/s against the dense MFMA peak (it is a latency chain: n/64 dependent steps)
+    n_sys = C * d
+    if "schur" in kernels:
+        sec = kernels["schur"]["ms_total"] / kernels["schur"]["launches"] * 1e-3
+        gb = 2.0 * int(be.st.n_pairs) * 3 * d * 8
+        kernels["schur"].update(gather_bytes_per_launch=gb, gather_GBps=round(gb / sec / 1e9, 1), bound="gather latency")
+    if "chol" in kernels:
+        sec = kernels["chol"]["ms_total"] / kernels["chol"]["launches"] * 1e-3
+        fl = n_sys ** 3 / 3.0
+        kernels["chol"].update(flop_per_launch=fl, TFLOPs=round(fl / sec / 1e12, 2),
+                               frac_of_fp64_mfma_peak=round(fl / sec / 1e12 / FP64_MFMA_PEAK_TFLOPS, 4),
+                               bound="latency (%d dependent 64-column steps)" % ((n_sys + 63) // 64))
 
     # ------------------------------------------------------------------ secondary: the north_star's 2x(6+3) shape
     ba_d6 = None
