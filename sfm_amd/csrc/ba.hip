@@ -527,41 +527,67 @@ __global__ __launch_bounds__(256) void k_schur_items(const int* __restrict__ xcd
                                                      const int* __restrict__ item_end,
                                                      const int* __restrict__ pair_k, const int* __restrict__ pair_k2,
                                                      const double* __restrict__ G, double* __restrict__ part) {
-  const int lane = threadIdx.x & 63;
+  // Gathers are latency-bound (about 5 us under load), so what counts is useful bytes in flight per register:
+  // a G block is 3 D doubles = CH 16-byte chunks, one lane fetches one chunk (global_load_dwordx4) and one
+  // instruction fetches BPL whole blocks (D = 10: 4 blocks on 60 lanes, D = 6: 7 on 63) - twice the bytes per
+  // VGPR of a one-double-per-lane gather that only 30 of 64 lanes take part in.  The blocks then pass through a
+  // wave-private LDS slab to reach the MFMA operand layout (lane = (row, m)).
+  constexpr int BLK = 3 * D;                   // doubles per G block
+  constexpr int CH = BLK / 2;                  // 16-byte chunks per block
+  constexpr int BPL = 64 / CH;                 // blocks per load instruction
+  constexpr int U = 4;                         // load instructions in flight per operand
+  constexpr int PB = U * BPL;                  // pairs per batch
+  __shared__ double s_stage[4][2][BPL * BLK];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   // workgroup b serves item group b % 8 (block rows c = b % 8 mod 8): with the round-robin XCD placement one
   // XCD sees every item of a camera's block row, so that camera's G blocks (1.2 MB at 5,000 observations) are
   // re-read from its 4 MB L2 instead of the fabric (speed only - any placement gives the same result)
   const int grp = blockIdx.x & 7;
-  const int pos = xcd_ptr[grp] + (blockIdx.x >> 3) * 4 + (threadIdx.x >> 6);
+  const int pos = xcd_ptr[grp] + (blockIdx.x >> 3) * 4 + w;
   if (pos >= xcd_ptr[grp + 1]) return;
   const int it = xcd_items[pos];
   const int beg = item_beg[it], end = item_end[it];
   const int row = lane & 15, m = lane >> 4;
   const bool valid = (row < D) && (m < 3);
   const int off = valid ? m * D + row : 0;
+  const int lb = lane / CH, lc = lane - lb * CH;          // this lane's block / chunk within a load
+  const bool loader = lb < BPL;
+  double* sA = s_stage[w][0];
+  double* sB = s_stage[w][1];
   v4d acc = {0.0, 0.0, 0.0, 0.0};
   for (int base = beg; base < end; base += 64) {
     const int idx = base + lane;
     const int kk = idx < end ? pair_k[idx] : 0;
     const int kk2 = idx < end ? pair_k2[idx] : 0;
     const int cnt = (end - base) < 64 ? (end - base) : 64;
-    int u = 0;
-    for (; u + 8 <= cnt; u += 8) {
-      double a[8], b[8];
+    for (int u0 = 0; u0 < cnt; u0 += PB) {
+      double2 ra[U], rb[U];
 #pragma unroll
-      for (int t = 0; t < 8; ++t) {
-        const int k = __builtin_amdgcn_readlane(kk, u + t), k2 = __builtin_amdgcn_readlane(kk2, u + t);
-        a[t] = valid ? G[(size_t)k * (3 * D) + off] : 0.0;
-        b[t] = valid ? G[(size_t)k2 * (3 * D) + off] : 0.0;
+      for (int t = 0; t < U; ++t) {
+        const int p = u0 + t * BPL + lb;                  // pair this lane fetches a chunk of
+        const int k = __shfl(kk, p & 63, 64), k2 = __shfl(kk2, p & 63, 64);
+        const bool ok = loader && p < cnt;
+        ra[t] = ok ? *(const double2*)(G + (size_t)k * BLK + 2 * lc) : make_double2(0.0, 0.0);
+        rb[t] = ok ? *(const double2*)(G + (size_t)k2 * BLK + 2 * lc) : make_double2(0.0, 0.0);
       }
 #pragma unroll
-      for (int t = 0; t < 8; ++t) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[t], b[t], acc, 0, 0, 0);
-    }
-    for (; u < cnt; ++u) {
-      const int k = __builtin_amdgcn_readlane(kk, u), k2 = __builtin_amdgcn_readlane(kk2, u);
-      const double a = valid ? G[(size_t)k * (3 * D) + off] : 0.0;
-      const double b = valid ? G[(size_t)k2 * (3 * D) + off] : 0.0;
-      acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
+      for (int t = 0; t < U; ++t) {
+        if (u0 + t * BPL >= cnt) break;                   // wave-uniform
+        if (loader) {
+          *(double2*)(sA + lb * BLK + 2 * lc) = ra[t];
+          *(double2*)(sB + lb * BLK + 2 * lc) = rb[t];
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+        for (int bb = 0; bb < BPL; ++bb) {
+          if (u0 + t * BPL + bb >= cnt) break;            // wave-uniform
+          const double a = valid ? sA[bb * BLK + off] : 0.0;
+          const double b = valid ? sB[bb * BLK + off] : 0.0;
+          acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");     // the slab is rewritten by the next t
+      }
     }
   }
   const int col = lane & 15;
