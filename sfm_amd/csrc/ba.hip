@@ -535,7 +535,7 @@ __global__ __launch_bounds__(256) void k_schur_items(const int* __restrict__ xcd
   constexpr int BLK = 3 * D;                   // doubles per G block
   constexpr int CH = BLK / 2;                  // 16-byte chunks per block
   constexpr int BPL = 64 / CH;                 // blocks per load instruction
-  constexpr int U = 4;                         // load instructions in flight per operand
+  constexpr int U = 8;                         // load instructions in flight per operand (16 costs occupancy: measured slower)
   constexpr int PB = U * BPL;                  // pairs per batch
   __shared__ double s_stage[4][2][BPL * BLK];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
