@@ -9,6 +9,7 @@ struct DenseWs {
   double* inv64;   // [2*ceil(n/128)][64][64] inverses of the 64x64 diagonal blocks
   int* flag;       // set to 1 when a pivot is not positive
   double* Lm;      // [(n+1)][n] the factor (lower part; row n = L^-1 rhs when the input carried a bordered row)
+  double* LmT;     // [n][n] transposed copy of the sub-diagonal blocks of the factor (the forward solve reads columns)
 };
 
 int64_t dense_ws_doubles(int n);

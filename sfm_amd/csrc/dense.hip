@@ -51,7 +51,7 @@ __device__ __forceinline__ double wave_sum_d(double v) {
 
 int64_t dense_ws_doubles(int n) {
   const int64_t nb = (n + 127) / 128;
-  return 2 * 64 * 64 + 2 * nb * 128 * 128 + nb * 2 * 64 * 64 + 32 + align_up((int64_t)(n + 1) * n, 32);
+  return 2 * 64 * 64 + 2 * nb * 128 * 128 + nb * 2 * 64 * 64 + 32 + align_up((int64_t)(n + 1) * n, 32) + (int64_t)n * n;
 }
 void dense_ws_carve(double* base, int n, DenseWs* w) {
   const int64_t nb = (n + 127) / 128;
@@ -61,7 +61,8 @@ void dense_ws_carve(double* base, int n, DenseWs* w) {
   w->DinvT = p; p += nb * 128 * 128;
   w->inv64 = p; p += nb * 2 * 64 * 64;
   w->flag = (int*)p; p += 32;
-  w->Lm = p;
+  w->Lm = p; p += align_up((int64_t)(n + 1) * n, 32);
+  w->LmT = p;
 }
 
 // ------------------------------------------------------------------------------------ Cholesky
@@ -381,9 +382,9 @@ __device__ __forceinline__ void trsm_rows16(const TrsmIn& in, const double* __re
 // A's panel columns are only read here (never overwritten), which is what makes step 1 race-free.
 constexpr int CHOL_STEP_SMEM = CRIT64_DOUBLES + 6 + 64 * LDM;     // 102.5 KB static (gfx950 allows up to 160 KB)
 // tile b of the step at panel j0 (see k_chol_step); all 256 threads of the workgroup, smem = CHOL_STEP_SMEM doubles
-__device__ __forceinline__ void chol_tile(double* smem, int b, bool stage_d, double* A, double* __restrict__ Lm, int n,
-                                          int nrows, int j0, const double* D, double* Dn, double* inv64_next,
-                                          int* __restrict__ fail) {
+__device__ __forceinline__ void chol_tile(double* smem, int b, bool stage_d, double* A, double* __restrict__ Lm,
+                                          double* __restrict__ LmT, int n, int nrows, int j0, const double* D, double* Dn,
+                                          double* inv64_next, int* __restrict__ fail) {
   double* sI = smem;                 // [64][LDM]
   double* sJ = smem + 64 * LDM;      // [64][LDM]   (the factor's buffers later reuse sI/sJ)
   double* sD = smem + CRIT64_DOUBLES + 6;
@@ -426,12 +427,30 @@ __device__ __forceinline__ void chol_tile(double* smem, int b, bool stage_d, dou
         if (gr < nrows && col < nb) Lm[(size_t)gr * n + j0 + col] = xi[t][i];
       }
   }
+  const bool has_tile10 = rem_c > 0 && rem_r > 64;         // tile (1,0) exists in this launch
+  if (tj == 0 && !(ti == 0 && has_tile10)) {
+    // transposed copy for the forward solve, from the LDS tile so that the stores run along rows of LmT.  The
+    // rows of tile (0,0) - the workgroup that carries the serial chain - are written by tile (1,0), which has
+    // the same rows as its X_J
+    for (int e = tid; e < 64 * 64; e += 256) {
+      const int col = e >> 6, r = e & 63;
+      const int gr = j1 + I0 + r;
+      if (gr < n && col < nb) LmT[(size_t)(j0 + col) * n + gr] = sI[r * LDM + col];
+    }
+  }
   PHASE_T(2);
   if (rem_c <= 0) return;                          // only the bordered row was left: nothing to update
   const double* sJr = sI;
   if (ti != tj) {
     trsm_rows16(inJ, sD, sJ + w * 16 * LDM, lane, xj);
     sJr = sJ;
+    if (ti == 1 && tj == 0) {
+      for (int e = tid; e < 64 * 64; e += 256) {
+        const int col = e >> 6, r = e & 63;
+        const int gr = j1 + r;
+        if (gr < n && col < nb) LmT[(size_t)(j0 + col) * n + gr] = sJ[r * LDM + col];
+      }
+    }
   }
   v4d acc[4];
 #pragma unroll
@@ -479,11 +498,11 @@ __device__ __forceinline__ void chol_tile(double* smem, int b, bool stage_d, dou
               [&](int r, int cc, double v) { Dn[r * 64 + cc] = v; }, fail);
 }
 
-__global__ __launch_bounds__(256) void k_chol_step(double* A, double* __restrict__ Lm, int n, int nrows, int j0,
-                                                   const double* D, double* Dn, double* inv64_next,
+__global__ __launch_bounds__(256) void k_chol_step(double* A, double* __restrict__ Lm, double* __restrict__ LmT, int n,
+                                                   int nrows, int j0, const double* D, double* Dn, double* inv64_next,
                                                    int* __restrict__ fail) {
   __shared__ double smem[CHOL_STEP_SMEM];
-  chol_tile(smem, (int)blockIdx.x, true, A, Lm, n, nrows, j0, D, Dn, inv64_next, fail);
+  chol_tile(smem, (int)blockIdx.x, true, A, Lm, LmT, n, nrows, j0, D, Dn, inv64_next, fail);
 }
 
 // Off-diagonal quadrant of each 64x64 diagonal-block inverse, for the triangular solves:
@@ -660,9 +679,9 @@ __global__ __launch_bounds__(256) void k_trsv_step(const double* __restrict__ L,
 constexpr int TRSV_FLOW_MAX_BLOCKS = 128;
 __device__ __forceinline__ bool trsv_pending(double v) { return __double_as_longlong(v) == -1LL; }
 template <bool TRANSPOSE>
-__global__ __launch_bounds__(256) void k_trsv_flow(const double* __restrict__ L, int n, const double* __restrict__ Dinv,
-                                                   const double* __restrict__ DinvT, const double* __restrict__ b,
-                                                   double* __restrict__ xout) {
+__global__ __launch_bounds__(256) void k_trsv_flow(const double* __restrict__ L, const double* __restrict__ LT, int n,
+                                                   const double* __restrict__ Dinv, const double* __restrict__ DinvT,
+                                                   const double* __restrict__ b, double* __restrict__ xout) {
   __shared__ double sM[128 * 128];
   __shared__ double sacc[128], sx[128], shalf[128];
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -685,8 +704,8 @@ __global__ __launch_bounds__(256) void k_trsv_flow(const double* __restrict__ L,
   // The 128x128 tile of L that couples block `blk` to this block does not depend on any flag: it is loaded into
   // registers BEFORE waiting for x_blk, so after the hand-off only LDS reads and FMAs remain on the chain.
   //   TRANSPOSE: lt[c] = L[rb + 64 h + c][r0 + i]      (column i of this block: coalesced over i)
-  //   forward  : lt[c] = L[r0 + i][rb + 64 h + c]      (row i of this block: 512 contiguous bytes per thread;
-  //              uncoalesced, but these loads are issued ahead of the hand-off and are off the chain)
+  //   forward  : lt[c] = L[r0 + i][rb + 64 h + c] read from the transposed copy LT[rb + 64 h + c][r0 + i] the
+  //              factorisation leaves behind (LT == nullptr: from L itself, 512 contiguous bytes per thread)
   double lt[64];
   auto load_tile = [&](int blk) {
     const int rb = blk * 128;
@@ -696,9 +715,9 @@ __global__ __launch_bounds__(256) void k_trsv_flow(const double* __restrict__ L,
 #pragma unroll
       for (int c = 0; c < 64; ++c) lt[c] = (i < nbg && h * 64 + c < nbb) ? lp[(size_t)c * n] : 0.0;
     } else {
-      const double* lp = L + (size_t)(r0 + i) * n + rb + h * 64;              // earlier blocks are full
+      const double* lp = LT + (size_t)(rb + h * 64) * n + r0 + i;             // earlier blocks are full
 #pragma unroll
-      for (int c = 0; c < 64; ++c) lt[c] = (i < nbg) ? lp[c] : 0.0;
+      for (int c = 0; c < 64; ++c) lt[c] = (i < nbg) ? lp[(size_t)c * n] : 0.0;
     }
   };
   if (first != g) load_tile(first);
@@ -752,7 +771,7 @@ int dense_cholesky(sfm_ctx* h, double* A, int n, int nrows, const DenseWs& w) {
     double* D = w.Ld + (size_t)(step & 1) * 64 * 64;
     double* Dn = w.Ld + (size_t)((step + 1) & 1) * 64 * 64;
     // tiles of the trailing matrix; with no trailing columns left (j1 == n) only the bordered row is solved
-    hipLaunchKernelGGL(k_chol_step, dim3(j1 < n ? T * (T + 1) / 2 : T), dim3(256), 0, h->stream, A, w.Lm, n, nrows, j0,
+    hipLaunchKernelGGL(k_chol_step, dim3(j1 < n ? T * (T + 1) / 2 : T), dim3(256), 0, h->stream, A, w.Lm, w.LmT, n, nrows, j0,
                        D, Dn, w.inv64 + (size_t)(j1 / 64) * 64 * 64, w.flag);
   }
   // 64x64 and then 128x128 diagonal-block inverses for the triangular solves
@@ -773,9 +792,9 @@ int dense_trsv(sfm_ctx* h, int n, const DenseWs& w, double* b, double* xout, int
     if (hipMemsetAsync(xout, 0xFF, (size_t)n * sizeof(double), h->stream) != hipSuccess)     // "not published yet"
       return sfm_fail(h, SFM_ERR_HIP, "dense_trsv", "memset");
     if (transpose)
-      hipLaunchKernelGGL(k_trsv_flow<true>, dim3(8 * nblk), dim3(256), 0, h->stream, L, n, w.Dinv, w.DinvT, b, xout);
+      hipLaunchKernelGGL(k_trsv_flow<true>, dim3(8 * nblk), dim3(256), 0, h->stream, L, w.LmT, n, w.Dinv, w.DinvT, b, xout);
     else
-      hipLaunchKernelGGL(k_trsv_flow<false>, dim3(8 * nblk), dim3(256), 0, h->stream, L, n, w.Dinv, w.DinvT, b, xout);
+      hipLaunchKernelGGL(k_trsv_flow<false>, dim3(8 * nblk), dim3(256), 0, h->stream, L, w.LmT, n, w.Dinv, w.DinvT, b, xout);
     SFM_LAUNCH_CHECK(h, "dense_trsv");
     return SFM_OK;
   }
@@ -812,6 +831,14 @@ extern "C" int sfm_dense_cholesky(sfm_handle h, double* a, int32_t n, int32_t* f
   return rc;
 }
 
+// test helper only: LT[c][r] = L[r][c] (the factorisation writes this copy itself)
+__global__ __launch_bounds__(256) void k_transpose_copy(const double* __restrict__ L, int n, double* __restrict__ LT) {
+  const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (e >= (int64_t)n * n) return;
+  const int r = (int)(e / n), c = (int)(e - (int64_t)r * n);
+  LT[(size_t)c * n + r] = L[e];
+}
+
 extern "C" int sfm_dense_trsv(sfm_handle h, const double* l, int32_t n, double* b, int transpose) {
   if (!h || !l || !b || n < 1) return SFM_ERR_ARG;
   double* base = nullptr;
@@ -819,6 +846,7 @@ extern "C" int sfm_dense_trsv(sfm_handle h, const double* l, int32_t n, double* 
   DenseWs w; dense_ws_carve(base, n, &w);
   double* xout = base + dense_ws_doubles(n);
   SFM_HIP(h, hipMemcpyAsync(w.Lm, l, (size_t)n * n * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+  hipLaunchKernelGGL(k_transpose_copy, dim3(cdiv((int64_t)n * n, 256)), dim3(256), 0, h->stream, l, n, w.LmT);
   const unsigned nb128 = cdiv(n, 128);
   hipLaunchKernelGGL(k_inv64, dim3(2 * nb128), dim3(64), 0, h->stream, l, n, w.inv64);
   hipLaunchKernelGGL(k_inv_merge, dim3(nb128), dim3(256), 0, h->stream, l, n, w.inv64, w.Dinv, w.DinvT);
