@@ -190,6 +190,30 @@ def test_product_path_fails_loudly_without_gpu():
     from sfm_amd import _lib, matcher
     with pytest.raises(_lib.SfmError):
         matcher.knn2(np.zeros((4, 128), np.uint8), np.zeros((4, 128), np.uint8))
+    # the driver rows too - and add_new_matches must not swallow that error the way it swallows data problems
+    from sfm_amd import driver
+    with pytest.raises(_lib.SfmError):
+        driver.associate(np.zeros((3, 2)), np.zeros((4, 2), np.float32))
+    with pytest.raises(_lib.SfmError):
+        driver.triangulate_two_view(np.zeros((2, 3, 4)), [0], [1], [[1.0, 2.0]], [[3.0, 4.0]])
+    with pytest.raises(_lib.SfmError):
+        driver.symmetric_epipolar_errors([np.zeros((2, 2), np.float32)], [np.zeros((2, 2), np.float32)], [np.eye(3)])
+
+
+def test_add_new_matches_lets_a_missing_gpu_through(tmp_path):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from sfm_amd import _lib
+    from sfm_amd.reconstruction import StructureFromMotion
+    s = StructureFromMotion(tmp_path)
+    s.corr_dir.mkdir(parents=True)
+    np.save(s.corr_dir / "pair_1_2_pts1.npy", np.float32([[10, 20], [30, 40]]))
+    np.save(s.corr_dir / "pair_1_2_pts2.npy", np.float32([[11, 21], [31, 41]]))
+    s.poses = {1: (np.eye(3), np.zeros((3, 1))), 2: (np.eye(3), np.array([[-1.0], [0], [0]]))}
+    with pytest.raises(_lib.SfmError):
+        s.add_new_matches("pair_1_2", 2)
+    assert s.add_new_matches("pair_7_8", 8) is False          # missing files: a data problem, reference semantics
 
 
 def test_product_code_never_imports_the_oracle():
