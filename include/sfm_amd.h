@@ -131,6 +131,9 @@ typedef struct {
   int64_t reduce_lin_off, reduce_lin_count;     /* doubles: [gc copy (n) | cost | ||gp||^2 | diag(B) (n)], n = n_cams*cam_dim  SUM */
   int64_t gmax_off;                              /* 2 doubles: max |gp|, max diag(C_j)                       MAX */
   int64_t reduce_S_off, reduce_S_count;         /* doubles: [S (n x n, n = n_cams*cam_dim) | r (n)]          SUM */
+  int64_t reduce_Sp_off, reduce_Sp_count;       /* doubles: lower triangle of S by rows, then r: n(n+1)/2 + n - what
+                                                   sfm_ba_pack_system fills and sfm_ba_unpack_system reads (the factorisation
+                                                   only reads the lower triangle, so ranks exchange half the bytes) SUM */
   int64_t reduce_q_off, reduce_q_count;         /* doubles: [rhs2 (n) | ||p_pts||^2 | p_pts^T C_a^-1 p_pts]  SUM */
   int64_t reduce_step_off, reduce_step_count;   /* doubles: [||J~ s||^2 | f~^T J~ s | cost(x+s) | ||s_pts||^2 | ||x_pts+s_pts||^2 ] SUM */
   int64_t pc_off, pp_off;           /* camera / point part of p = -(H + alpha I)^-1 g */
@@ -159,6 +162,9 @@ int sfm_ba_finish_linearize(sfm_handle h, const sfm_ba_problem* p);
 
 /* Damped solve in three stages around two reductions. */
 int sfm_ba_schur_build(sfm_handle h, const sfm_ba_problem* p, double alpha);          /* -> reduce_S (partial) */
+/* Multi-rank only: reduce_S (lower triangle + r) -> reduce_Sp before the all-reduce, and back after it. */
+int sfm_ba_pack_system(sfm_handle h, const sfm_ba_problem* p);
+int sfm_ba_unpack_system(sfm_handle h, const sfm_ba_problem* p);
 int sfm_ba_schur_solve(sfm_handle h, const sfm_ba_problem* p, double alpha, int want_q); /* chol, p_c, p_p; -> reduce_q (partial) */
 int sfm_ba_finish_solve(sfm_handle h, const sfm_ba_problem* p, int want_q);              /* scalars PNORM2 (and PQ) */
 

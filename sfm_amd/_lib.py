@@ -34,7 +34,7 @@ class BAProblem(C.Structure):
 class BALayout(C.Structure):
     _fields_ = [(n, i64) for n in (
         "total_bytes", "rec_off", "rec_stride", "recB_off", "B_off", "gc_off", "Cp_off", "gp_off",
-        "reduce_lin_off", "reduce_lin_count", "gmax_off", "reduce_S_off", "reduce_S_count",
+        "reduce_lin_off", "reduce_lin_count", "gmax_off", "reduce_S_off", "reduce_S_count", "reduce_Sp_off", "reduce_Sp_count",
         "reduce_q_off", "reduce_q_count", "reduce_step_off", "reduce_step_count",
         "pc_off", "pp_off", "scalars_off", "G_off")]
 
@@ -59,6 +59,8 @@ SIGNATURES = {
     "sfm_ba_linearize": (C.c_int, [vp, C.POINTER(BAProblem), vp]),
     "sfm_ba_finish_linearize": (C.c_int, [vp, C.POINTER(BAProblem)]),
     "sfm_ba_schur_build": (C.c_int, [vp, C.POINTER(BAProblem), f64]),
+    "sfm_ba_pack_system": (C.c_int, [vp, C.POINTER(BAProblem)]),
+    "sfm_ba_unpack_system": (C.c_int, [vp, C.POINTER(BAProblem)]),
     "sfm_ba_schur_solve": (C.c_int, [vp, C.POINTER(BAProblem), f64, C.c_int]),
     "sfm_ba_finish_solve": (C.c_int, [vp, C.POINTER(BAProblem), C.c_int]),
     "sfm_ba_step": (C.c_int, [vp, C.POINTER(BAProblem), vp, f64, vp]),

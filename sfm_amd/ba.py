@@ -108,7 +108,10 @@ class GpuBA:
         wq = 1 if want_q else 0
         self.h.call("sfm_ba_schur_build", self._pp, C.c_double(alpha))
         if self.comm.world_size > 1 or getattr(self.comm, 'force', False):
-            self.comm.allreduce_sum(self.view(L.reduce_S_off, L.reduce_S_count))
+            # the factorisation reads only the lower triangle of S: ranks exchange n(n+1)/2 + n doubles, not n^2 + n
+            self.h.call("sfm_ba_pack_system", self._pp)
+            self.comm.allreduce_sum(self.view(L.reduce_Sp_off, L.reduce_Sp_count))
+            self.h.call("sfm_ba_unpack_system", self._pp)
         self.h.call("sfm_ba_schur_solve", self._pp, C.c_double(alpha), wq)
         if self.comm.world_size > 1 or getattr(self.comm, 'force', False):
             self.comm.allreduce_sum(self.view(L.reduce_q_off, L.reduce_q_count))

@@ -82,6 +82,8 @@ extern "C" int sfm_ba_get_layout(int32_t n_cams, int32_t n_pts, int64_t n_obs, i
   out->reduce_lin_off = L.red_lin * 8; out->reduce_lin_count = 2 * n + 2;
   out->gmax_off = L.gmax * 8;
   out->reduce_S_off = L.red_S * 8; out->reduce_S_count = n * n + n;
+  out->reduce_Sp_off = (L.dense + dense_ws_lm_offset((int)n)) * 8;   // the factor's buffer: free until the factorisation
+  out->reduce_Sp_count = n * (n + 1) / 2 + n;
   out->reduce_q_off = L.red_q * 8; out->reduce_q_count = n + 2;
   out->reduce_step_off = L.red_step * 8; out->reduce_step_count = 5;
   out->pc_off = L.pc * 8; out->pp_off = L.pp * 8;
@@ -1046,6 +1048,30 @@ extern "C" int sfm_ba_schur_build(sfm_handle h, const sfm_ba_problem* p, double 
   SFM_LAUNCH_CHECK(h, "sfm_ba_schur_build");
   return SFM_OK;
 }
+
+// rows 0..n of [S | r] ([n+1][n]): row r keeps its first min(r + 1, n) entries, packed back to back
+__global__ __launch_bounds__(256) void k_pack_lower(const double* __restrict__ S, int n, double* __restrict__ Sp, int unpack_dir) {
+  const int r = blockIdx.x;
+  const int len = r < n ? r + 1 : n;
+  const size_t off = (size_t)r * (r + 1) / 2;
+  double* full = const_cast<double*>(S) + (size_t)r * n;
+  for (int c = threadIdx.x; c < len; c += 256) {
+    if (unpack_dir) full[c] = Sp[off + c];
+    else Sp[off + c] = full[c];
+  }
+}
+
+static int pack_S(sfm_handle h, const sfm_ba_problem* p, int unpack_dir, const char* what) {
+  Lay L; int rc = check_problem(h, p, &L); if (rc) return rc;
+  double* ws = (double*)p->workspace;
+  const int n = p->n_cams * p->cam_dim;
+  DenseWs dw; dense_ws_carve(WS(L, dense), n, &dw);
+  hipLaunchKernelGGL(k_pack_lower, dim3(n + 1), dim3(256), 0, h->stream, WS(L, red_S), n, dw.Lm, unpack_dir);
+  SFM_LAUNCH_CHECK(h, what);
+  return SFM_OK;
+}
+extern "C" int sfm_ba_pack_system(sfm_handle h, const sfm_ba_problem* p) { return pack_S(h, p, 0, "sfm_ba_pack_system"); }
+extern "C" int sfm_ba_unpack_system(sfm_handle h, const sfm_ba_problem* p) { return pack_S(h, p, 1, "sfm_ba_unpack_system"); }
 
 extern "C" int sfm_ba_schur_solve(sfm_handle h, const sfm_ba_problem* p, double alpha, int want_q) {
   Lay L; int rc = check_problem(h, p, &L); if (rc) return rc;

@@ -13,6 +13,7 @@ struct DenseWs {
 };
 
 int64_t dense_ws_doubles(int n);
+int64_t dense_ws_lm_offset(int n);   // offset (doubles) of DenseWs::Lm inside the workspace
 void dense_ws_carve(double* base, int n, DenseWs* out);
 // Lower Cholesky of the leading n x n of A ([nrows][n] row-major, nrows = n or n + 1: a last row is carried
 // along as a right-hand side and leaves as L^-1 rhs).  The factor goes to w.Lm (A's trailing part is

@@ -53,6 +53,10 @@ int64_t dense_ws_doubles(int n) {
   const int64_t nb = (n + 127) / 128;
   return 2 * 64 * 64 + 2 * nb * 128 * 128 + nb * 2 * 64 * 64 + 32 + align_up((int64_t)(n + 1) * n, 32) + (int64_t)n * n;
 }
+int64_t dense_ws_lm_offset(int n) {
+  const int64_t nb = (n + 127) / 128;
+  return 2 * 64 * 64 + 2 * nb * 128 * 128 + nb * 2 * 64 * 64 + 32;
+}
 void dense_ws_carve(double* base, int n, DenseWs* w) {
   const int64_t nb = (n + 127) / 128;
   double* p = base;
@@ -61,7 +65,7 @@ void dense_ws_carve(double* base, int n, DenseWs* w) {
   w->DinvT = p; p += nb * 128 * 128;
   w->inv64 = p; p += nb * 2 * 64 * 64;
   w->flag = (int*)p; p += 32;
-  w->Lm = p; p += align_up((int64_t)(n + 1) * n, 32);
+  w->Lm = p; p += align_up((int64_t)(n + 1) * n, 32);      // = base + dense_ws_lm_offset(n)
   w->LmT = p;
 }
 
