@@ -92,6 +92,8 @@ CASES = [
     ("c10p100_n05", 10, 100, None, 0.5, 0.02, 0.0, 14),
     ("c8p60_L4",    8,  60, 4,    0.5, 0.02, 0.01, 15),
     ("c6p40_cam",   6,  40, None, 0.3, 0.01, 0.005, 16),
+    ("c15p200_L6",  15, 200, 6,   0.5, 0.02, 0.005, 17),
+    ("c20p300_L5",  20, 300, 5,   0.7, 0.015, 0.008, 18),
 ]
 
 
