@@ -14,6 +14,8 @@
 //                    the step data [Li11 0; L21 Li22] (trsm_rows16, MFMA), applies the rank-64 update, and the
 //                    workgroup of tile (0,0) factors the next diagonal block right away (LOOK-AHEAD).  The
 //                    factor is written to a separate matrix Lm; the panel columns of A stay read-only.
+//   k_syrk_lower   : systems from n = 4096 work in 256-column strips: the steps of a strip only update the strip's
+//                    columns, this kernel applies the strip's rank-256 update to the rest (4x the flops per byte)
 //   k_inv64_fix / k_inv_merge : explicit inverses of the 128x128 diagonal blocks of L (both layouts), so that
 //   k_trsv_flow    : a whole triangular solve is one launch of n/128 workgroups handing their 128 unknowns
 //                    on through the output vector itself (k_trsv_step: one launch per block, for n > 16384).
@@ -275,34 +277,33 @@ __device__ __forceinline__ void crit64_lite(const Crit64& c, int tid, FL store_L
 // Step data of one diagonal block as the step kernel reads it: D [64][64] row-major =
 // [Li11 0; L21 Li22] (32x32 quadrants; identity-padded when the block is short).
 // Factor the first 64x64 diagonal block: L -> Lm, step data -> D, diagonal 32-block inverses -> inv64.
-__device__ __forceinline__ void chol_first_block(double* smem, const double* __restrict__ A, double* __restrict__ Lm, int n,
-                                                 double* __restrict__ D, double* __restrict__ inv64, int* __restrict__ fail) {
+__device__ __forceinline__ void chol_diag_block(double* smem, const double* __restrict__ A, double* __restrict__ Lm, int n,
+                                                int j, double* __restrict__ D, double* __restrict__ inv64,
+                                                int* __restrict__ fail) {
   const Crit64 c = crit64_carve(smem);
   const int tid = threadIdx.x;
-  const int nb = n < 64 ? n : 64;
+  const int nb = (n - j) < 64 ? (n - j) : 64;
+  const double* Ab = A + (size_t)j * n + j;
+  double* Lb = Lm + (size_t)j * n + j;
   for (int e = tid; e < 64 * 64; e += 256) {
     const int r = e >> 6, cc = e & 63;
-    c.sM[r * LDM + cc] = (r < nb && cc < nb) ? ((cc <= r) ? A[(size_t)r * n + cc] : 0.0) : ((r == cc) ? 1.0 : 0.0);
+    c.sM[r * LDM + cc] = (r < nb && cc < nb) ? ((cc <= r) ? Ab[(size_t)r * n + cc] : 0.0) : ((r == cc) ? 1.0 : 0.0);
   }
   __syncthreads();
   crit64_lite(c, tid,
-              [&](int r, int cc, double v) { if (r < nb && cc < nb) Lm[(size_t)r * n + cc] = v; },
+              [&](int r, int cc, double v) { if (r < nb && cc < nb) Lb[(size_t)r * n + cc] = v; },
               [&](int r, int cc, double v) { D[r * 64 + cc] = v; inv64[r * 64 + cc] = v; },
               [&](int r, int cc, double v) { D[r * 64 + cc] = v; }, fail);
 }
-__global__ __launch_bounds__(256) void k_chol_first(const double* __restrict__ A, double* __restrict__ Lm, int n,
-                                                    double* __restrict__ D, double* __restrict__ inv64,
-                                                    int* __restrict__ fail) {
+// Factor the 64x64 diagonal block at (j, j) on its own (the first block; in the two-level scheme the first block
+// of every 256-column strip): L -> Lm, step data -> D, diagonal 32-block inverses -> inv64 (block j / 64).
+__global__ __launch_bounds__(256) void k_chol_diag(const double* __restrict__ A, double* __restrict__ Lm, int n, int j,
+                                                   double* __restrict__ D, double* __restrict__ inv64,
+                                                   int* __restrict__ fail) {
   __shared__ double smem[CRIT64_DOUBLES + 6];     // static: with `extern __shared__` hipcc needs 256 + 68 registers here
-  chol_first_block(smem, A, Lm, n, D, inv64, fail);
+  chol_diag_block(smem, A, Lm, n, j, D, inv64, fail);
 }
 
-// X = A_rows L_jj^-T for the 16 rows [row, row + 16) of this wavefront, 64 columns, in two 32-wide stages on
-// v_mfma_f64_16x16x4_f64:   X1 = A1 Li11^T;   X2 = (A2 - X1 L21^T) Li22^T.
-// sD = step data [64][LDM] in LDS; dst = this wave's 16 rows of an LDS tile [.][LDM]: X lands there (the MFMA
-// result layout has to become an A-operand layout between the stages, which is a round trip through dst) and
-// in x[4] (C layout: row = kq + 4 i, column = 16 t + r16).  All four wavefronts call this together
-// (__syncthreads inside).  Rows >= nrows and columns >= nb read as zero.
 struct TrsmIn {
   double a1[8];        // A1 as MFMA A operand: row r16, k = 4 s + kq
   double a2c[2][4];    // A2 in the result layout: row kq + 4 i, column 32 + 16 t + r16
@@ -385,22 +386,37 @@ __device__ __forceinline__ void trsm_rows16(const TrsmIn& in, const double* __re
 //      publishes its step data to Dn for the next launch, so the serial chain never waits for a kernel of its own.
 // A's panel columns are only read here (never overwritten), which is what makes step 1 race-free.
 constexpr int CHOL_STEP_SMEM = CRIT64_DOUBLES + 6 + 64 * LDM;     // 102.5 KB static (gfx950 allows up to 160 KB)
+constexpr int CHOL_STRIP_MIN_N = 4096;       // systems at least this large use the two-level (strip + rank-256 update) scheme
 // tile b of the step at panel j0 (see k_chol_step); all 256 threads of the workgroup, smem = CHOL_STEP_SMEM doubles
+// col_end < n (two-level scheme): only the trailing columns [j1, col_end) of the current 256-column strip are
+// updated (tiles enumerated column by column); the rest waits for the strip's rank-256 update (k_syrk_lower).
 __device__ __forceinline__ void chol_tile(double* smem, int b, bool stage_d, double* A, double* __restrict__ Lm,
-                                          double* __restrict__ LmT, int n, int nrows, int j0, const double* D, double* Dn,
-                                          double* inv64_next, int* __restrict__ fail) {
+                                          double* __restrict__ LmT, int n, int nrows, int j0, int col_end, const double* D,
+                                          double* Dn, double* inv64_next, int* __restrict__ fail) {
   double* sI = smem;                 // [64][LDM]
   double* sJ = smem + 64 * LDM;      // [64][LDM]   (the factor's buffers later reuse sI/sJ)
   double* sD = smem + CRIT64_DOUBLES + 6;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-  // 1-D order over the lower-triangular tiles only: b -> (ti, tj), tj <= ti, b = ti (ti + 1) / 2 + tj
-  int ti = (int)((sqrtf(8.0f * (float)b + 1.0f) - 1.0f) * 0.5f);
-  while ((ti + 1) * (ti + 2) / 2 <= b) ++ti;
-  while (ti * (ti + 1) / 2 > b) --ti;
-  const int tj = b - ti * (ti + 1) / 2;
   const int nb = (n - j0) < 64 ? (n - j0) : 64;
   const int j1 = j0 + nb;
-  const int rem_r = nrows - j1, rem_c = n - j1;
+  const int rem_r = nrows - j1, rem_c = col_end - j1;
+  int ti, tj;
+  if (rem_c <= 0) {                     // no columns to update: one tile per 64 rows, panel solve only
+    ti = b; tj = 0;
+  } else if (col_end >= n) {
+    // 1-D order over the lower-triangular tiles only: b -> (ti, tj), tj <= ti, b = ti (ti + 1) / 2 + tj
+    ti = (int)((sqrtf(8.0f * (float)b + 1.0f) - 1.0f) * 0.5f);
+    while ((ti + 1) * (ti + 2) / 2 <= b) ++ti;
+    while (ti * (ti + 1) / 2 > b) --ti;
+    tj = b - ti * (ti + 1) / 2;
+  } else {
+    // strip: column tj holds the tiles ti = tj .. T - 1, columns one after the other (at most 4 of them)
+    const int T = (rem_r + 63) / 64;
+    tj = 0;
+    int rest = b;
+    while (rest >= T - tj) { rest -= T - tj; ++tj; }
+    ti = tj + rest;
+  }
   const int I0 = ti * 64, J0 = tj * 64;
   const int col16 = lane & 15, rq = lane >> 4;
   // prefetch the C tile this lane updates (rows 16 w + (lane>>4) + 4 i, cols 16 t + (lane&15))
@@ -503,10 +519,105 @@ __device__ __forceinline__ void chol_tile(double* smem, int b, bool stage_d, dou
 }
 
 __global__ __launch_bounds__(256) void k_chol_step(double* A, double* __restrict__ Lm, double* __restrict__ LmT, int n,
-                                                   int nrows, int j0, const double* D, double* Dn, double* inv64_next,
-                                                   int* __restrict__ fail) {
+                                                   int nrows, int j0, int col_end, const double* D, double* Dn,
+                                                   double* inv64_next, int* __restrict__ fail) {
   __shared__ double smem[CHOL_STEP_SMEM];
-  chol_tile(smem, (int)blockIdx.x, true, A, Lm, LmT, n, nrows, j0, D, Dn, inv64_next, fail);
+  chol_tile(smem, (int)blockIdx.x, true, A, Lm, LmT, n, nrows, j0, col_end, D, Dn, inv64_next, fail);
+}
+
+// Rank-K update of the trailing matrix after a 256-column strip (two-level scheme, large systems):
+//   C[r][c] -= sum_k X[r][k] X[c][k],  r < R rows, c < Cn columns, c <= r,  X = the strip's columns of the factor.
+// 128x128 tiles, 256 threads = 2x2 wavefronts of 64x64 (4x4 accumulators of v_mfma_f64_16x16x4_f64), K in chunks
+// of 32 staged through LDS (row stride 34 doubles = conflict-free operand reads); the next chunk's global loads
+// are in flight while the current one is multiplied.  1-D grid over the lower-triangular tiles.
+__global__ __launch_bounds__(256) void k_syrk_lower(double* __restrict__ C, int ldc, const double* __restrict__ X, int ldx,
+                                                    int R, int Cn, int K) {
+  constexpr int KC = 32, LDK = 34;
+  __shared__ double sA[128 * LDK], sB[128 * LDK];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int wr = w >> 1, wc = w & 1;
+  int ti = (int)((sqrtf(8.0f * (float)blockIdx.x + 1.0f) - 1.0f) * 0.5f);
+  while ((ti + 1) * (ti + 2) / 2 <= (int)blockIdx.x) ++ti;
+  while (ti * (ti + 1) / 2 > (int)blockIdx.x) --ti;
+  const int tj = (int)blockIdx.x - ti * (ti + 1) / 2;
+  const int I0 = ti * 128, J0 = tj * 128;
+  const bool diag = ti == tj;
+  const int lr = tid >> 1, lc = (tid & 1) * 16;          // this thread stages 16 doubles of row lr
+  double2 ra[8], rb[8];
+  const bool vec2 = ((ldx & 1) == 0) && ((reinterpret_cast<uintptr_t>(X) & 15) == 0);     // 16-byte loads need even strides
+  auto load_chunk = [&](int k0) {
+    // rows past the end read row 0 and are zeroed by the select: straight-line loads instead of a branch per load
+    const int ga = I0 + lr, gb = J0 + lr;
+    const bool oka = ga < R, okb = !diag && gb < Cn;
+    const double* pa = X + (size_t)(oka ? ga : 0) * ldx + k0 + lc;
+    const double* pb = X + (size_t)(okb ? gb : 0) * ldx + k0 + lc;
+    if (vec2 && k0 + KC <= K) {
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const double2 va = *(const double2*)(pa + 2 * q), vb = *(const double2*)(pb + 2 * q);
+        ra[q] = oka ? va : make_double2(0.0, 0.0);
+        rb[q] = okb ? vb : make_double2(0.0, 0.0);
+      }
+    } else {
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const int kk = k0 + lc + 2 * q;
+        ra[q].x = (oka && kk < K) ? pa[2 * q] : 0.0;      ra[q].y = (oka && kk + 1 < K) ? pa[2 * q + 1] : 0.0;
+        rb[q].x = (okb && kk < K) ? pb[2 * q] : 0.0;      rb[q].y = (okb && kk + 1 < K) ? pb[2 * q + 1] : 0.0;
+      }
+    }
+  };
+  v4d acc[4][4];
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) acc[a][b] = (v4d){0.0, 0.0, 0.0, 0.0};
+  const double* sBr = diag ? sA : sB;
+  const int r16 = lane & 15, kq = lane >> 4;
+  load_chunk(0);
+  for (int k0 = 0; k0 < K; k0 += KC) {
+    __syncthreads();                                     // the previous chunk has been consumed
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      *(double2*)(sA + lr * LDK + lc + 2 * q) = ra[q];
+      if (!diag) *(double2*)(sB + lr * LDK + lc + 2 * q) = rb[q];
+    }
+    __syncthreads();
+    if (k0 + KC < K) load_chunk(k0 + KC);
+#pragma unroll
+    for (int ks = 0; ks < KC; ks += 4) {
+      double a[4], b[4];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        a[t] = sA[(wr * 64 + t * 16 + r16) * LDK + ks + kq];
+        b[t] = sBr[(wc * 64 + t * 16 + r16) * LDK + ks + kq];
+      }
+#pragma unroll
+      for (int rt = 0; rt < 4; ++rt)
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct) acc[rt][ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[rt], b[ct], acc[rt][ct], 0, 0, 0);
+    }
+  }
+  // read-modify-write of C in batches of 16 values: all loads of a batch are issued before its first store (a
+  // load after a store through the same pointer would otherwise wait for it - 64 serialised round trips)
+#pragma unroll
+  for (int rt = 0; rt < 4; ++rt) {
+    double cold[4][4];
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int gr = I0 + wr * 64 + rt * 16 + kq + 4 * i, gc = J0 + wc * 64 + ct * 16 + r16;
+        cold[ct][i] = (gr < R && gc < Cn && gc <= gr) ? C[(size_t)gr * ldc + gc] : 0.0;
+      }
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int gr = I0 + wr * 64 + rt * 16 + kq + 4 * i, gc = J0 + wc * 64 + ct * 16 + r16;
+        if (gr < R && gc < Cn && gc <= gr) C[(size_t)gr * ldc + gc] = cold[ct][i] - acc[rt][ct][i];
+      }
+  }
 }
 
 // Off-diagonal quadrant of each 64x64 diagonal-block inverse, for the triangular solves:
@@ -764,19 +875,39 @@ int dense_cholesky(sfm_ctx* h, double* A, int n, int nrows, const DenseWs& w) {
   if (hipMemsetAsync(w.Ld, 0, (size_t)2 * 64 * 64 * sizeof(double), h->stream) != hipSuccess ||
       hipMemsetAsync(w.inv64, 0, (size_t)((n + 127) / 128) * 2 * 64 * 64 * sizeof(double), h->stream) != hipSuccess)
     return sfm_fail(h, SFM_ERR_HIP, "dense_cholesky", "memset");
-  hipLaunchKernelGGL(k_chol_first, dim3(1), dim3(256), 0, h->stream, A, w.Lm, n, w.Ld, w.inv64, w.flag);
+  // Two-level scheme from CHOL_STRIP_MIN_N on: inside a 256-column strip the 64-column steps only touch the
+  // strip's own columns, the rest of the trailing matrix gets ONE rank-256 update per strip (k_syrk_lower) - 4x the
+  // flops per byte streamed from HBM.  Small systems are a pure latency chain and keep the one-level scheme.
+  const char* strip_env = getenv("SFM_CHOL_STRIP_MIN_N");       // test knob
+  const int strip_min_n = strip_env ? atoi(strip_env) : CHOL_STRIP_MIN_N;
+  const int strip = n >= strip_min_n ? 256 : n;
   int step = 0;
-  for (int j0 = 0; j0 < n; j0 += 64, ++step) {
-    const int nb = (n - j0) < 64 ? (n - j0) : 64;
-    const int j1 = j0 + nb;
-    const int below = nrows - j1;
-    if (below <= 0) break;
-    const unsigned T = cdiv(below, 64);
-    double* D = w.Ld + (size_t)(step & 1) * 64 * 64;
-    double* Dn = w.Ld + (size_t)((step + 1) & 1) * 64 * 64;
-    // tiles of the trailing matrix; with no trailing columns left (j1 == n) only the bordered row is solved
-    hipLaunchKernelGGL(k_chol_step, dim3(j1 < n ? T * (T + 1) / 2 : T), dim3(256), 0, h->stream, A, w.Lm, w.LmT, n, nrows, j0,
-                       D, Dn, w.inv64 + (size_t)(j1 / 64) * 64 * 64, w.flag);
+  for (int jb = 0; jb < n; jb += strip) {
+    const int je = (jb + strip) < n ? (jb + strip) : n;            // columns [jb, je) form this strip
+    hipLaunchKernelGGL(k_chol_diag, dim3(1), dim3(256), 0, h->stream, A, w.Lm, n, jb, w.Ld + (size_t)(step & 1) * 64 * 64,
+                       w.inv64 + (size_t)(jb / 64) * 64 * 64, w.flag);
+    for (int j0 = jb; j0 < je; j0 += 64, ++step) {
+      const int nb = (n - j0) < 64 ? (n - j0) : 64;
+      const int j1 = j0 + nb;
+      const int below = nrows - j1;
+      if (below <= 0) break;
+      const unsigned T = cdiv(below, 64);
+      double* D = w.Ld + (size_t)(step & 1) * 64 * 64;
+      double* Dn = w.Ld + (size_t)((step + 1) & 1) * 64 * 64;
+      const int tcols = (int)cdiv(je - j1 > 0 ? je - j1 : 0, 64);  // tile columns still inside the strip
+      unsigned grid;
+      if (tcols == 0) grid = T;                                    // panel solve only (strip end / bordered row)
+      else if (je >= n) grid = T * (T + 1) / 2;                    // last (or only) strip: the whole trailing triangle
+      else { grid = 0; for (int c = 0; c < tcols; ++c) grid += T - c; }
+      hipLaunchKernelGGL(k_chol_step, dim3(grid), dim3(256), 0, h->stream, A, w.Lm, w.LmT, n, nrows, j0, je, D, Dn,
+                         w.inv64 + (size_t)(j1 / 64) * 64 * 64, w.flag);
+    }
+    if (je < n) {
+      const int R = nrows - je, Cn = n - je;
+      const unsigned T2 = cdiv(R, 128);
+      hipLaunchKernelGGL(k_syrk_lower, dim3(T2 * (T2 + 1) / 2), dim3(256), 0, h->stream, A + (size_t)je * n + je, n,
+                         w.Lm + (size_t)je * n + jb, n, R, Cn, je - jb);
+    }
   }
   // 64x64 and then 128x128 diagonal-block inverses for the triangular solves
   const unsigned nb64 = cdiv(n, 64), nb128 = cdiv(n, 128);
