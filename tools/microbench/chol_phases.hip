@@ -9,8 +9,8 @@
 #include <cmath>
 #include <random>
 
-int main() {
-  const int n = 2000;
+int main(int argc, char** argv) {
+  const int n = argc > 1 ? atoi(argv[1]) : 2000;
   std::vector<double> A((size_t)(n + 1) * n);
   std::mt19937_64 rng(1);
   std::normal_distribution<double> nd;
