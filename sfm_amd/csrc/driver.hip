@@ -246,8 +246,10 @@ __global__ __launch_bounds__(256) void k_triangulate2(const double* __restrict__
 }
 
 // ------------------------------------------------------------------------------- epipolar verification
-__device__ __forceinline__ float div_rn_f32(float a, float b) { return (float)((double)a / (double)b); }
-__device__ __forceinline__ float sqrt_rn_f32(float a) { return (float)sqrt((double)a); }
+// hipcc's float `/` and sqrtf are correctly rounded by default (-fhip-fp32-correctly-rounded-divide-sqrt); the
+// bit-exact tests against NumPy on the 148 shipped pairs and on random data hold it to that
+__device__ __forceinline__ float div_rn_f32(float a, float b) { return a / b; }
+__device__ __forceinline__ float sqrt_rn_f32(float a) { return __builtin_sqrtf(a); }
 
 // line = M x with M = F (lines in image 2 of points in image 1) or F^T; cv2.computeCorrespondEpilines
 __device__ __forceinline__ void epiline(const double* __restrict__ f, bool transpose, float2 pt, float& la,
