@@ -545,25 +545,22 @@ __global__ __launch_bounds__(256) void k_syrk_lower(double* __restrict__ C, int 
   const int lr = tid >> 1, lc = (tid & 1) * 16;          // this thread stages 16 doubles of row lr
   double2 ra[8], rb[8];
   const bool vec2 = ((ldx & 1) == 0) && ((reinterpret_cast<uintptr_t>(X) & 15) == 0);     // 16-byte loads need even strides
+  // rows past the end read row 0 and are zeroed when the registers go to LDS - a select right after the load would
+  // make the compiler wait for the data at once and lose the overlap with the MFMAs of the current chunk
+  const int ga = I0 + lr, gb = J0 + lr;
+  const bool oka = ga < R, okb = !diag && gb < Cn;
+  const double* rowa = X + (size_t)(oka ? ga : 0) * ldx + lc;
+  const double* rowb = X + (size_t)(okb ? gb : 0) * ldx + lc;
   auto load_chunk = [&](int k0) {
-    // rows past the end read row 0 and are zeroed by the select: straight-line loads instead of a branch per load
-    const int ga = I0 + lr, gb = J0 + lr;
-    const bool oka = ga < R, okb = !diag && gb < Cn;
-    const double* pa = X + (size_t)(oka ? ga : 0) * ldx + k0 + lc;
-    const double* pb = X + (size_t)(okb ? gb : 0) * ldx + k0 + lc;
     if (vec2 && k0 + KC <= K) {
 #pragma unroll
-      for (int q = 0; q < 8; ++q) {
-        const double2 va = *(const double2*)(pa + 2 * q), vb = *(const double2*)(pb + 2 * q);
-        ra[q] = oka ? va : make_double2(0.0, 0.0);
-        rb[q] = okb ? vb : make_double2(0.0, 0.0);
-      }
+      for (int q = 0; q < 8; ++q) { ra[q] = *(const double2*)(rowa + k0 + 2 * q); rb[q] = *(const double2*)(rowb + k0 + 2 * q); }
     } else {
 #pragma unroll
       for (int q = 0; q < 8; ++q) {
         const int kk = k0 + lc + 2 * q;
-        ra[q].x = (oka && kk < K) ? pa[2 * q] : 0.0;      ra[q].y = (oka && kk + 1 < K) ? pa[2 * q + 1] : 0.0;
-        rb[q].x = (okb && kk < K) ? pb[2 * q] : 0.0;      rb[q].y = (okb && kk + 1 < K) ? pb[2 * q + 1] : 0.0;
+        ra[q].x = kk < K ? rowa[k0 + 2 * q] : 0.0;      ra[q].y = kk + 1 < K ? rowa[k0 + 2 * q + 1] : 0.0;
+        rb[q].x = kk < K ? rowb[k0 + 2 * q] : 0.0;      rb[q].y = kk + 1 < K ? rowb[k0 + 2 * q + 1] : 0.0;
       }
     }
   };
@@ -579,8 +576,8 @@ __global__ __launch_bounds__(256) void k_syrk_lower(double* __restrict__ C, int 
     __syncthreads();                                     // the previous chunk has been consumed
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
-      *(double2*)(sA + lr * LDK + lc + 2 * q) = ra[q];
-      if (!diag) *(double2*)(sB + lr * LDK + lc + 2 * q) = rb[q];
+      *(double2*)(sA + lr * LDK + lc + 2 * q) = oka ? ra[q] : make_double2(0.0, 0.0);
+      if (!diag) *(double2*)(sB + lr * LDK + lc + 2 * q) = okb ? rb[q] : make_double2(0.0, 0.0);
     }
     __syncthreads();
     if (k0 + KC < K) load_chunk(k0 + KC);
