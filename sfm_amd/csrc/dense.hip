@@ -527,12 +527,16 @@ __global__ __launch_bounds__(256) void k_chol_step(double* A, double* __restrict
 
 // Rank-K update of the trailing matrix after a 256-column strip (two-level scheme, large systems):
 //   C[r][c] -= sum_k X[r][k] X[c][k],  r < R rows, c < Cn columns, c <= r,  X = the strip's columns of the factor.
-// 128x128 tiles, 256 threads = 2x2 wavefronts of 64x64 (4x4 accumulators of v_mfma_f64_16x16x4_f64), K in chunks
+// 128x128 tiles, 512 threads = 4x2 wavefronts of 32x64 (2x4 accumulators of v_mfma_f64_16x16x4_f64), K in chunks
 // of 32 staged through LDS (row stride 34 doubles = conflict-free operand reads); the next chunk's global loads
 // are in flight while the current one is multiplied.  1-D grid over the lower-triangular tiles.
-__global__ __launch_bounds__(256) void k_syrk_lower(double* __restrict__ C, int ldc, const double* __restrict__ X, int ldx,
-                                                    int R, int Cn, int K) {
+template <int NW>   // wavefronts per workgroup: 4 (each 64x64 of the tile) or 8 (each 32x64: half the registers, twice the occupancy)
+__device__ __forceinline__ void syrk_lower_body(double* __restrict__ C, int ldc, const double* __restrict__ X, int ldx,
+                                                int R, int Cn, int K) {
   constexpr int KC = 32, LDK = 34;
+  constexpr int NT = NW * 64;                 // threads
+  constexpr int RT = NW == 8 ? 2 : 4;         // 16-row MFMA tiles per wavefront
+  constexpr int QN = 128 * KC / 2 / NT;       // double2 loads per thread and operand per chunk: 8 (256 thr) or 4 (512 thr)
   __shared__ double sA[128 * LDK], sB[128 * LDK];
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int wr = w >> 1, wc = w & 1;
@@ -542,8 +546,9 @@ __global__ __launch_bounds__(256) void k_syrk_lower(double* __restrict__ C, int 
   const int tj = (int)blockIdx.x - ti * (ti + 1) / 2;
   const int I0 = ti * 128, J0 = tj * 128;
   const bool diag = ti == tj;
-  const int lr = tid >> 1, lc = (tid & 1) * 16;          // this thread stages 16 doubles of row lr
-  double2 ra[8], rb[8];
+  constexpr int TPR = NT / 128;                           // threads per staged row
+  const int lr = tid / TPR, lc = (tid % TPR) * (KC / TPR); // this thread stages KC / TPR doubles of row lr
+  double2 ra[QN], rb[QN];
   const bool vec2 = ((ldx & 1) == 0) && ((reinterpret_cast<uintptr_t>(X) & 15) == 0);     // 16-byte loads need even strides
   // rows past the end read row 0 and are zeroed when the registers go to LDS - a select right after the load would
   // make the compiler wait for the data at once and lose the overlap with the MFMAs of the current chunk
@@ -554,28 +559,29 @@ __global__ __launch_bounds__(256) void k_syrk_lower(double* __restrict__ C, int 
   auto load_chunk = [&](int k0) {
     if (vec2 && k0 + KC <= K) {
 #pragma unroll
-      for (int q = 0; q < 8; ++q) { ra[q] = *(const double2*)(rowa + k0 + 2 * q); rb[q] = *(const double2*)(rowb + k0 + 2 * q); }
+      for (int q = 0; q < QN; ++q) { ra[q] = *(const double2*)(rowa + k0 + 2 * q); rb[q] = *(const double2*)(rowb + k0 + 2 * q); }
     } else {
 #pragma unroll
-      for (int q = 0; q < 8; ++q) {
+      for (int q = 0; q < QN; ++q) {
         const int kk = k0 + lc + 2 * q;
         ra[q].x = kk < K ? rowa[k0 + 2 * q] : 0.0;      ra[q].y = kk + 1 < K ? rowa[k0 + 2 * q + 1] : 0.0;
         rb[q].x = kk < K ? rowb[k0 + 2 * q] : 0.0;      rb[q].y = kk + 1 < K ? rowb[k0 + 2 * q + 1] : 0.0;
       }
     }
   };
-  v4d acc[4][4];
+  v4d acc[RT][4];
 #pragma unroll
-  for (int a = 0; a < 4; ++a)
+  for (int a = 0; a < RT; ++a)
 #pragma unroll
     for (int b = 0; b < 4; ++b) acc[a][b] = (v4d){0.0, 0.0, 0.0, 0.0};
   const double* sBr = diag ? sA : sB;
   const int r16 = lane & 15, kq = lane >> 4;
+  const int row0 = wr * (RT * 16);                        // first tile row of this wavefront
   load_chunk(0);
   for (int k0 = 0; k0 < K; k0 += KC) {
     __syncthreads();                                     // the previous chunk has been consumed
 #pragma unroll
-    for (int q = 0; q < 8; ++q) {
+    for (int q = 0; q < QN; ++q) {
       *(double2*)(sA + lr * LDK + lc + 2 * q) = oka ? ra[q] : make_double2(0.0, 0.0);
       if (!diag) *(double2*)(sB + lr * LDK + lc + 2 * q) = okb ? rb[q] : make_double2(0.0, 0.0);
     }
@@ -583,14 +589,13 @@ __global__ __launch_bounds__(256) void k_syrk_lower(double* __restrict__ C, int 
     if (k0 + KC < K) load_chunk(k0 + KC);
 #pragma unroll
     for (int ks = 0; ks < KC; ks += 4) {
-      double a[4], b[4];
+      double a[RT], b[4];
 #pragma unroll
-      for (int t = 0; t < 4; ++t) {
-        a[t] = sA[(wr * 64 + t * 16 + r16) * LDK + ks + kq];
-        b[t] = sBr[(wc * 64 + t * 16 + r16) * LDK + ks + kq];
-      }
+      for (int t = 0; t < RT; ++t) a[t] = sA[(row0 + t * 16 + r16) * LDK + ks + kq];
 #pragma unroll
-      for (int rt = 0; rt < 4; ++rt)
+      for (int t = 0; t < 4; ++t) b[t] = sBr[(wc * 64 + t * 16 + r16) * LDK + ks + kq];
+#pragma unroll
+      for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
         for (int ct = 0; ct < 4; ++ct) acc[rt][ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[rt], b[ct], acc[rt][ct], 0, 0, 0);
     }
@@ -598,23 +603,30 @@ __global__ __launch_bounds__(256) void k_syrk_lower(double* __restrict__ C, int 
   // read-modify-write of C in batches of 16 values: all loads of a batch are issued before its first store (a
   // load after a store through the same pointer would otherwise wait for it - 64 serialised round trips)
 #pragma unroll
-  for (int rt = 0; rt < 4; ++rt) {
+  for (int rt = 0; rt < RT; ++rt) {
     double cold[4][4];
 #pragma unroll
     for (int ct = 0; ct < 4; ++ct)
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        const int gr = I0 + wr * 64 + rt * 16 + kq + 4 * i, gc = J0 + wc * 64 + ct * 16 + r16;
+        const int gr = I0 + row0 + rt * 16 + kq + 4 * i, gc = J0 + wc * 64 + ct * 16 + r16;
         cold[ct][i] = (gr < R && gc < Cn && gc <= gr) ? C[(size_t)gr * ldc + gc] : 0.0;
       }
 #pragma unroll
     for (int ct = 0; ct < 4; ++ct)
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        const int gr = I0 + wr * 64 + rt * 16 + kq + 4 * i, gc = J0 + wc * 64 + ct * 16 + r16;
+        const int gr = I0 + row0 + rt * 16 + kq + 4 * i, gc = J0 + wc * 64 + ct * 16 + r16;
         if (gr < R && gc < Cn && gc <= gr) C[(size_t)gr * ldc + gc] = cold[ct][i] - acc[rt][ct][i];
       }
   }
+}
+
+// 8 wavefronts of 32x64 each (142 registers: measured 5 % faster than 4 wavefronts of 64x64 at 248; forcing 128
+// registers for a second resident workgroup spills and loses it again)
+__global__ __launch_bounds__(512) void k_syrk_lower(double* __restrict__ C, int ldc, const double* __restrict__ X, int ldx,
+                                                    int R, int Cn, int K) {
+  syrk_lower_body<8>(C, ldc, X, ldx, R, Cn, K);
 }
 
 // Off-diagonal quadrant of each 64x64 diagonal-block inverse, for the triangular solves:
@@ -902,7 +914,7 @@ int dense_cholesky(sfm_ctx* h, double* A, int n, int nrows, const DenseWs& w) {
     if (je < n) {
       const int R = nrows - je, Cn = n - je;
       const unsigned T2 = cdiv(R, 128);
-      hipLaunchKernelGGL(k_syrk_lower, dim3(T2 * (T2 + 1) / 2), dim3(256), 0, h->stream, A + (size_t)je * n + je, n,
+      hipLaunchKernelGGL(k_syrk_lower, dim3(T2 * (T2 + 1) / 2), dim3(512), 0, h->stream, A + (size_t)je * n + je, n,
                          w.Lm + (size_t)je * n + jb, n, R, Cn, je - jb);
     }
   }
