@@ -164,7 +164,8 @@ def main():
         fl = n_sys ** 3 / 3.0
         kernels["chol"].update(flop_per_launch=fl, TFLOPs=round(fl / sec / 1e12, 2),
                                frac_of_fp64_mfma_peak=round(fl / sec / 1e12 / FP64_MFMA_PEAK_TFLOPS, 4),
-                               bound="latency (%d dependent 64-column steps)" % ((n_sys + 63) // 64))
+                               bound=("latency (%d dependent 64-column steps)" % ((n_sys + 63) // 64)) if n_sys < 4096
+                               else "mfma (256-column strips + rank-256 trailing updates)")
 
     # ------------------------------------------------------------------ secondary: the north_star's 2x(6+3) shape
     ba_d6 = None
