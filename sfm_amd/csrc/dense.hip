@@ -808,7 +808,7 @@ __global__ __launch_bounds__(256) void k_trsv_flow(const double* __restrict__ L,
                                                    const double* __restrict__ b, double* __restrict__ xout) {
   __shared__ double sM[128 * 128];
   __shared__ double sacc[128], sx[128], shalf[128];
-  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int tid = threadIdx.x;
   const int nblk = (n + 127) / 128;
   const int p = (int)blockIdx.x >> 3;                                          // position in the dependency order
   if (((int)blockIdx.x & 7) != ((p >> 5) & 7)) return;
