@@ -78,6 +78,29 @@ def test_associate_segments_ragged_and_empty(gpu_ready):
     assert got[-1][0].size == 600 * 500
 
 
+def test_associate_random_segment_layouts(gpu_ready):
+    """40 random launches: 1-12 segments of 0-700 tracks x 0-400 correspondences each (empty ones included), so
+    segment boundaries fall anywhere inside the 256-row blocks and the column splits."""
+    from oracle import driver_oracle as do
+    from sfm_amd import driver
+    rng = np.random.default_rng(2024)
+    for trial in range(40):
+        n_seg = int(rng.integers(1, 13))
+        tl, cl = [], []
+        for _ in range(n_seg):
+            T = int(rng.integers(0, 701)) if rng.random() > 0.15 else 0
+            M = int(rng.integers(0, 401)) if rng.random() > 0.15 else 0
+            c = pixels(rng, M)
+            tl.append(pixels(rng, T, c).astype(np.float64)); cl.append(c)
+        got = driver.associate_segments(tl, cl)
+        for (rows, cols), t, c in zip(got, tl, cl):
+            if len(t) and len(c):
+                r0, c0 = do.associate(t, c)
+            else:
+                r0 = c0 = np.zeros(0, np.int64)
+            assert np.array_equal(rows, r0) and np.array_equal(cols, c0), (trial, len(t), len(c))
+
+
 def test_associate_large_properties(gpu_ready):
     """100,000 tracks x 20,000 correspondences (2e9 pair tests): transposing the problem gives the
     transposed pair set, and sampled rows equal the oracle."""
