@@ -258,3 +258,45 @@ def test_c_matcher_equals_numpy_oracle():
     d1, d2 = synth.make_descriptors(300, 500, seed=2)
     got = ba_c.knn2_u8(d1.astype(np.uint8), d2.astype(np.uint8))
     assert all(np.array_equal(a, b) for a, b in zip(got, mo.knn2(d1, d2)))
+
+
+# ------------------------------------------------------------------ harness parts pinned by the reference (a5, a10)
+def _pack_stats_cases():
+    from sfm_amd import synth
+    g = dict(np.load(os.path.join(GOLDEN, "pack_stats.npz"), allow_pickle=False))
+    b = dict(np.load(os.path.join(GOLDEN, "bunny_state.npz"), allow_pickle=False))
+    ids = [int(i) for i in b["ids"]]
+    poses = {k: (b["R"][i], b["t"][i].reshape(3, 1)) for i, k in enumerate(ids)}
+    tracks = [dict() for _ in range(b["pts"].shape[0])]
+    for k in range(len(b["cam_idx"])):
+        tracks[int(b["pt_idx"][k])][ids[int(b["cam_idx"][k])]] = b["uv"][k].tolist()
+    K = np.array([[1228, 0, 512], [0, 1228, 384], [0, 0, 1]], dtype=np.float64)
+    cases = {"bunny": (poses, b["pts"].tolist(), tracks, K)}
+    for name, (C, P, L, seed) in {"c7p60": (7, 60, None, 31), "c12p150_L4": (12, 150, 4, 32)}.items():
+        cases[name] = synth.make_scene(C, P, obs_per_point=L, seed=seed, noise_px=0.8, pt_sigma=0.02, cam_sigma=0.005).state()
+    return g, cases
+
+
+def test_packing_equals_what_the_reference_packs():
+    """pack_state (product host code) against the arrays captured from the closure of the reference's own
+    bundle_adjust (tests/golden/make_golden_stats.py): observation order, indices, pixels, x0."""
+    from sfm_amd.reconstruction import pack_state
+    g, cases = _pack_stats_cases()
+    for name, (poses, pts, tracks, K) in cases.items():
+        cams, p3, cam_idx, pt_idx, uv, ids = pack_state(poses, pts, tracks, K, cam_dim=10, order="aligned")
+        assert np.array_equal(cam_idx, g[f"{name}_camera_idxs"]), name
+        assert np.array_equal(pt_idx, g[f"{name}_point2D_idxs"]), name
+        assert np.array_equal(uv, g[f"{name}_points2D"]), name
+        x0 = np.concatenate([cams.ravel(), p3.ravel()])
+        assert np.max(np.abs(x0 - g[f"{name}_x0"]) / np.maximum(np.abs(g[f"{name}_x0"]), 1.0)) < 1e-12, name
+        assert ids == list(poses)
+
+
+def test_oracle_statistics_equal_the_reference_run():
+    from oracle import ba_oracle as bo
+    g, cases = _pack_stats_cases()
+    for name, (poses, pts, tracks, K) in cases.items():
+        st = bo.reconstruction_stats(poses, pts, tracks, K)
+        for k in ("mean_reproj_error", "max_reproj_error", "mean_track_length", "max_track_length"):
+            assert st[k] == pytest.approx(float(g[f"{name}_stat_{k}"]), rel=1e-12), (name, k)
+        assert st["num_points"] == int(g[f"{name}_stat_num_points"]) and st["num_cameras"] == int(g[f"{name}_stat_num_cameras"])
