@@ -325,17 +325,19 @@ __global__ __launch_bounds__(256) void k_point_blocks(int P, const int* __restri
 
 // per camera: B_c = sum Jc~^T Jc~ (DxD), g_c = sum Jc~^T f~ over the camera's observations.
 // One workgroup per chunk of <= 256 observations of one camera: the chunk's Jc~ rows and f~ are gathered into
-// LDS, thread e of each 128-thread half owns B[a][b] (or g[a]) over half of the chunk; the halves and then the
-// chunks of a camera are added in fixed order (k_cam_blocks_final).
+// LDS and contracted on the matrix cores; the chunks of a camera are added in fixed order (k_cam_blocks_final).
 template <int D>
 __global__ __launch_bounds__(256) void k_cam_blocks_chunks(const int* __restrict__ cch_beg, const int* __restrict__ cch_end,
                                                            const int* __restrict__ cam_obs,
                                                            const double* __restrict__ recA,
                                                            const double* __restrict__ recB, double* __restrict__ part) {
+  // [B | g] = M^T M restricted to rows < D, with M = [Jc~ | f~] (2 rows per observation, D + 1 columns): one 16x16
+  // tile of v_mfma_f64_16x16x4_f64 per wavefront, K = (observation, residual row), both operands the same LDS rows.
+  // Each wavefront takes a quarter of the chunk; the four partial tiles are added in fixed order.
   constexpr int W = 2 * D + 2, LDW = W + 1, NE = D * D + D;
   __shared__ double s[256 * LDW];
-  __shared__ double s_half[128];
-  const int ch = blockIdx.x, tid = threadIdx.x;
+  __shared__ double s_tile[4][16 * 17];
+  const int ch = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int beg = cch_beg[ch], cnt = cch_end[ch] - beg;
   for (int i = tid; i < cnt * W; i += 256) {
     const int o = i / W, q = i - o * W;
@@ -343,25 +345,26 @@ __global__ __launch_bounds__(256) void k_cam_blocks_chunks(const int* __restrict
     s[o * LDW + q] = (q < 2 * D) ? recA[(size_t)k * (2 * D) + q] : recB[(size_t)k * 8 + 6 + (q - 2 * D)];
   }
   __syncthreads();
-  const int e = tid & 127, half = tid >> 7;
-  const int o0 = half * ((cnt + 1) / 2), o1 = half ? cnt : ((cnt + 1) / 2);
-  double acc = 0.0;
-  if (e < D * D) {
-    const int a = e / D, b = e - a * D;
-    for (int o = o0; o < o1; ++o) {
-      const double* r = &s[o * LDW];
-      acc += r[a] * r[b] + r[D + a] * r[D + b];
-    }
-  } else if (e < NE) {
-    const int aa = e - D * D;
-    for (int o = o0; o < o1; ++o) {
-      const double* r = &s[o * LDW];
-      acc += r[aa] * r[2 * D] + r[D + aa] * r[2 * D + 1];
-    }
+  const int col = lane & 15, kq = lane >> 4;             // operand column (0..D-1: Jc~, D: f~), k slot
+  const int rrow = kq & 1;                               // residual row of this k slot
+  const int q = col < D ? rrow * D + col : 2 * D + rrow; // position inside an observation's staged record
+  const bool live = col <= D;
+  const int per = (cnt + 3) / 4;
+  const int o0 = w * per, o1 = (o0 + per) < cnt ? (o0 + per) : cnt;
+  v4d acc = {0.0, 0.0, 0.0, 0.0};
+  for (int o = o0; o < o1; o += 2) {                     // k slots: (o, row 0), (o, row 1), (o + 1, row 0), (o + 1, row 1)
+    const int oo = o + (kq >> 1);
+    const double v = (live && oo < o1) ? s[oo * LDW + q] : 0.0;
+    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(v, v, acc, 0, 0, 0);
   }
-  if (half == 1) s_half[e] = acc;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) s_tile[w][(kq + 4 * i) * 17 + col] = acc[i];      // C/D: row = kq + 4 i, column = col
   __syncthreads();
-  if (half == 0 && e < NE) part[(size_t)ch * NE + e] = acc + s_half[e];
+  if (tid < NE) {
+    const int a = tid < D * D ? tid / D : tid - D * D;
+    const int b = tid < D * D ? tid - a * D : D;
+    part[(size_t)ch * NE + tid] = ((s_tile[0][a * 17 + b] + s_tile[1][a * 17 + b]) + s_tile[2][a * 17 + b]) + s_tile[3][a * 17 + b];
+  }
 }
 template <int D>
 __global__ void k_cam_blocks_final(int C, const int* __restrict__ cch_ptr, const double* __restrict__ part,
