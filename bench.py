@@ -43,6 +43,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-matcher", action="store_true")
     ap.add_argument("--no-d6", action="store_true")
+    ap.add_argument("--no-mixed", action="store_true")
+    ap.add_argument("--no-dropin", action="store_true")
     ap.add_argument("--no-driver-rows", action="store_true")
     return ap.parse_args()
 
@@ -54,8 +56,7 @@ def main():
     from sfm_amd import synth, _lib
     from sfm_amd.ba import GpuBA
     from sfm_amd.comm import DistComm, LocalComm
-    from sfm_amd.structure import build_structure, partition_points, shard_arrays
-    from sfm_amd.trf import TRFState
+    from sfm_amd.structure import partition_points, shard_arrays
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -97,96 +98,144 @@ def main():
     # ------------------------------------------------------------------ BA workload (cfg4 by default)
     C, P, Lobs, d = args.cams, args.pts, args.obs_per_point, args.cam_dim
     sc = synth.make_scene(C, P, obs_per_point=Lobs, seed=1004, noise_px=0.5, pt_sigma=0.02, cam_sigma=0.002)
-    full = build_structure(sc.cam_idx, sc.pt_idx, C, P) if world == 1 else None
     lo, hi = (0, P)
     if world > 1:
         pt_ptr = np.zeros(P + 1, dtype=np.int64)
         np.cumsum(np.bincount(sc.pt_idx, minlength=P), out=pt_ptr[1:])
         lo, hi = partition_points(pt_ptr, world)[rank]
     ci, pi, uv, pts0 = shard_arrays(sc.cam_idx, sc.pt_idx, sc.uv, sc.pts0, lo, hi)
-    be = GpuBA(sc.cams0[:, :d], pts0, ci, pi, uv, synth.K_REF, device=local_rank, comm=comm,
-               structure=full)
     n_obs_total = sc.n_obs
-    st = TRFState(be, max_nfev=10 ** 9, check_tolerances=False)
-    cost0 = st.cost
-    be.h.set_profiling(True)
-    for _ in range(args.warmup):
-        st.outer()
-    be.h.profile()
-    solves0, nfev0 = st.n_solves, st.nfev
-    barrier_sync()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        st.outer()
-    barrier_sync()
-    elapsed = max_over_ranks(time.perf_counter() - t0)
-    prof = be.h.profile()
-    be.h.set_profiling(False)
-    n_solves = st.n_solves - solves0
-    n_trials = st.nfev - nfev0
-    value = args.steps / elapsed
-
-    # roofline of the Jacobian kernel: algorithmic bytes per observation:
-    # idx 8 + uv 16 + residual 16 + Jc 2*d*8 + Jp 48
-    bytes_per_obs = 8 + 16 + 16 + 2 * d * 8 + 48
-    lin_ms, lin_cnt = prof["lin_obs"]
-    roofline = None
-    if lin_cnt > 0:
-        per_launch_s = lin_ms / lin_cnt * 1e-3
-        achieved = bytes_per_obs * be.N / per_launch_s / 1e9
-        roofline = {"kernel": "k_lin_obs (residual + 2x(%d+3) Jacobian + Huber scaling)" % d, "bound": "hbm",
-                    "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
-                    "bytes_per_launch": bytes_per_obs * be.N, "avg_us": round(per_launch_s * 1e6, 2),
-                    "launches": lin_cnt}
-        # HBM bytes per launch from the PMC counters (rocprofv3 cannot run inside this process): taken from
-        # the committed summary of the same workload, collected and corrected as MI355X_MICROARCH.md prescribes
-        try:
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_summary.json")))
-            wl = pmc["workload"]
-            if world == 1 and (wl["cams"], wl["pts"], wl["obs"], wl["cam_dim"]) == (C, P, n_obs_total, d):
-                roofline["traffic"] = pmc["k_lin_obs"]["hbm_bytes_per_launch"]
-                roofline["traffic_source"] = "profiles/r01_pmc_summary.json (FETCH_SIZE x2 + WRITE_SIZE, separate --pmc passes)"
-        except (OSError, KeyError, ValueError):
-            pass
-    kernels = {k: {"ms_total": round(v[0], 3), "launches": v[1],
-                   "share": round(v[0] / (elapsed * 1e3), 4)} for k, v in prof.items() if v[1] > 0}
-    # the two kernels that dominate the TIME are not HBM- or MFMA-bound; their rates are
-    # reported for completeness: the Schur gather in bytes of G blocks it pulls through L2/MALL, the Cholesky
-    # in fp64 FLOP/s against the dense MFMA peak (it is a latency chain: n/64 dependent steps)
     n_sys = C * d
-    if "schur" in kernels:
-        sec = kernels["schur"]["ms_total"] / kernels["schur"]["launches"] * 1e-3
-        gb = 2.0 * int(be.st.n_pairs) * 3 * d * 8
-        kernels["schur"].update(gather_bytes_per_launch=gb, gather_GBps=round(gb / sec / 1e9, 1), bound="gather latency")
-    if "chol" in kernels:
-        sec = kernels["chol"]["ms_total"] / kernels["chol"]["launches"] * 1e-3
-        fl = n_sys ** 3 / 3.0
-        kernels["chol"].update(flop_per_launch=fl, TFLOPs=round(fl / sec / 1e12, 2),
-                               frac_of_fp64_mfma_peak=round(fl / sec / 1e12 / FP64_MFMA_PEAK_TFLOPS, 4),
-                               bound=("latency (%d dependent 64-column steps)" % ((n_sys + 63) // 64)) if n_sys < 4096
-                               else "mfma (256-column strips + rank-256 trailing updates)")
 
-    # ------------------------------------------------------------------ secondary: the north_star's 2x(6+3) shape
-    ba_d6 = None
-    if d == 10 and not args.no_d6:
-        be.h.set_profiling(False)
-        be6 = GpuBA(sc.cams0[:, :6], pts0, ci, pi, uv, synth.K_REF, device=local_rank, comm=comm, structure=be.st)
-        st6 = TRFState(be6, max_nfev=10 ** 9, check_tolerances=False)
+    def fixed_schedule_run(cam_dim, precision, profile):
+        """W warm-up + K timed outer iterations of the trust-region loop (library side, termination tests off)."""
+        be = GpuBA(sc.cams0[:, :cam_dim], pts0, ci, pi, uv, synth.K_REF, device=local_rank, comm=comm, precision=precision)
+        st = be.trf_begin(max_nfev=2 ** 31 - 1, check_tolerances=False)
+        cost0 = st.result().cost
         for _ in range(args.warmup):
-            st6.outer()
-        s0 = st6.n_solves
+            st.outer()
+        r0 = st.result()
+        if profile:
+            be.h.set_profiling(True)
+            be.h.profile()
         barrier_sync()
-        t6 = time.perf_counter()
+        t0 = time.perf_counter()
         for _ in range(args.steps):
-            st6.outer()
+            st.outer()
         barrier_sync()
-        e6 = max_over_ranks(time.perf_counter() - t6)
-        ba_d6 = {"value": args.steps / e6, "unit": "LM-iterations/s", "ms_per_step": e6 / args.steps * 1e3,
-                 "damped_solves": st6.n_solves - s0, "cost_end": st6.cost,
-                 "workload": "same scene, camera block [rvec,t] with fixed K (cam_dim 6, n = %d)" % (6 * C)}
-        del be6, st6
+        elapsed = max_over_ranks(time.perf_counter() - t0)
+        prof = None
+        if profile:
+            prof = be.h.profile()
+            be.h.set_profiling(False)
+        r1 = st.result()
+        st.close()
+        out = {"elapsed": elapsed, "value": args.steps / elapsed, "ms_per_step": elapsed / args.steps * 1e3,
+               "damped_solves": r1.n_solves - r0.n_solves, "trial_steps": r1.nfev - r0.nfev, "cost_start": cost0,
+               "cost_end": r1.cost, "n_pairs": be.n_pairs, "n_obs_local": be.N, "prof": prof}
+        del st, be
         torch.cuda.empty_cache()
+        return out
+
+    # the timed run carries NO per-kernel events; the kernel table comes from a second, identical pass
+    main = fixed_schedule_run(d, "fp64", profile=False)
+    elapsed, value = main["elapsed"], main["value"]
+    profd = fixed_schedule_run(d, "fp64", profile=True)
+    prof, prof_elapsed = profd["prof"], profd["elapsed"]
+    kernels = {k: {"ms_total": round(v[0], 3), "launches": v[1], "us_per_launch": round(v[0] / v[1] * 1e3, 2),
+                   "share": round(v[0] / (prof_elapsed * 1e3), 4)} for k, v in prof.items() if v[1] > 0}
+
+    # ---- rooflines (MI355X_MICROARCH.md peaks).  Algorithmic work per launch:
+    #   k_lin_obs     idx 8 + uv 16 + residual 16 + Jc 2*d*8 + Jp 48 bytes per observation (SURVEY.md section 8d)
+    #   Cholesky      n^3 / 3 fp64 FLOP per factorisation (all k_chol_* launches of one factorisation together)
+    #   k_schur_items 2 G blocks (3*d doubles each) gathered per camera pair - bytes through the L2/Infinity-Cache fabric
+    def pmc_traffic(kernel_key):
+        """HBM bytes per launch from the committed PMC summary of the same workload (rocprofv3 cannot run inside
+        this process); collected and corrected as MI355X_MICROARCH.md prescribes."""
+        for name in ("r02_pmc_summary.json", "r01_pmc_summary.json"):
+            try:
+                pmc = json.load(open(os.path.join(ROOT, "profiles", name)))
+                wl = pmc["workload"]
+                if world == 1 and (wl["cams"], wl["pts"], wl["obs"], wl["cam_dim"]) == (C, P, n_obs_total, d) and kernel_key in pmc:
+                    return pmc[kernel_key]["hbm_bytes_per_launch"], "profiles/" + name
+            except (OSError, KeyError, ValueError):
+                continue
+        return None, None
+
+    def roof(name, bound, work, unit_scale, peak, unit, slot, kernel_key=None, note=None):
+        if slot not in kernels:
+            return None
+        sec = kernels[slot]["us_per_launch"] * 1e-6
+        ach = work / sec / unit_scale
+        r = {"kernel": name, "bound": bound, "achieved": round(ach, 2), "peak": peak, "unit": unit,
+             "frac": round(ach / peak, 4), "traffic": None, "work_per_launch": work,
+             "avg_us": kernels[slot]["us_per_launch"], "launches": kernels[slot]["launches"],
+             "time_share": kernels[slot]["share"]}
+        if kernel_key:
+            r["traffic"], src = pmc_traffic(kernel_key)
+            if src:
+                r["traffic_source"] = src + " (FETCH_SIZE x2 + WRITE_SIZE, separate --pmc passes)"
+        if note:
+            r["note"] = note
+        return r
+
+    bytes_per_obs = 8 + 16 + 16 + 2 * d * 8 + 48
+    roofs = [
+        roof("k_chol_diag + k_chol_step (+ k_syrk_lower): bordered Cholesky of the reduced camera system, n = %d" % n_sys,
+             "mfma", n_sys ** 3 / 3.0, 1e12, FP64_MFMA_PEAK_TFLOPS, "TFLOP/s", "chol",
+             note=("latency chain of %d dependent 64-column steps" % ((n_sys + 63) // 64)) if n_sys < 4096
+             else "256-column strips + rank-256 trailing updates"),
+        roof("k_schur_items (S blocks = -sum G_k G_k2^T per camera pair) + assemble + rhs", "hbm",
+             2.0 * main["n_pairs"] * 3 * d * 8, 1e9, HBM_PEAK_GBS, "GB/s", "schur", "k_schur_items",
+             note="gather through L2 / Infinity Cache: bytes are the G blocks pulled per launch, not unique HBM bytes"),
+        roof("k_lin_obs (residual + 2x(%d+3) Jacobian + Huber scaling)" % d, "hbm", float(bytes_per_obs) * main["n_obs_local"],
+             1e9, HBM_PEAK_GBS, "GB/s", "lin_obs", "k_lin_obs"),
+    ]
+    roofs = [r for r in roofs if r]
+    # headline roofline object = the kernel (group) with the largest share of the step time
+    roofline = max(roofs, key=lambda r: r["time_share"]) if roofs else None
+
+    # ------------------------------------------------------------------ secondary BA figures on the same scene
+    def brief(r, what):
+        return {"value": r["value"], "unit": "LM-iterations/s", "ms_per_step": r["ms_per_step"],
+                "damped_solves": r["damped_solves"], "cost_end": r["cost_end"], "workload": what}
+    ba_d6 = ba_mixed = None
+    if d == 10 and not args.no_d6:
+        ba_d6 = brief(fixed_schedule_run(6, "fp64", False),
+                      "same scene, camera block [rvec,t] with fixed K (cam_dim 6, n = %d)" % (6 * C))
+    if not args.no_mixed:
+        rm = fixed_schedule_run(d, "mixed", True)
+        ba_mixed = brief(rm, "same scene and schedule, SFM_BA_MIXED: Jacobian rows and W L^-T stored in float32, "
+                             "all sums / S / solve in float64 (opt-in; the headline stays float64)")
+        ba_mixed["kernels_us"] = {k: round(v[0] / v[1] * 1e3, 2) for k, v in rm["prof"].items() if v[1] > 0}
+
+    # ------------------------------------------------------------------ end-to-end drop-in call (N = 1 only)
+    # wall clock of ONE StructureFromMotion.bundle_adjust() with the reference's settings (ftol = xtol = 1e-4,
+    # max_nfev = 100) on the same scene held in the reference's Python containers: dict walk + packing, problem
+    # construction on the device, the solve, write-back.  Not part of `value`.
+    dropin = None
+    if rank == 0 and world == 1 and not args.no_dropin:
+        try:
+            from sfm_amd.reconstruction import StructureFromMotion
+            s = StructureFromMotion(order="aligned", cam_dim=d, device=local_rank)
+            s.poses, s.points3D, s.point_tracks, s.K = sc.state()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            ret = s.bundle_adjust()
+            torch.cuda.synchronize()
+            wall = time.perf_counter() - t0
+            r = s.last_ba_result
+            dropin = {"bundle_adjust_wall_s": wall, "returned": None if ret is None else bool(ret),
+                      "phases_s": {k: round(v, 4) for k, v in s.last_ba_timing.items()},
+                      "nfev": r.nfev, "njev": r.njev, "status": r.status, "n_solves": r.n_solves,
+                      "workload": f"StructureFromMotion.bundle_adjust() on {C} cams / {P} pts / {n_obs_total} obs held as "
+                                  "dict / list state, reference solver settings"}
+            t0 = time.perf_counter()
+            s.compute_reconstruction_stats()
+            dropin["compute_reconstruction_stats_wall_s"] = time.perf_counter() - t0
+            del s
+        except Exception as e:       # a reported extra; never fail the main measurement on it
+            dropin = {"error": repr(e)}
 
     # ------------------------------------------------------------------ matcher workload (cfg2)
     matcher = None
@@ -197,20 +246,25 @@ def main():
         q_lo, q_hi = (rank * n) // world, ((rank + 1) * n) // world
         q = torch.from_numpy(d1[q_lo:q_hi].astype(np.uint8)).cuda()
         t = torch.from_numpy(d2.astype(np.uint8)).cuda()
-        be.h.set_profiling(True)
-        for _ in range(2):
+        hd = _lib.get_handle(local_rank)
+
+        def match_pass():
             i1, i2, a, b = mt.knn2(q, t, "l2", device=local_rank)
-            mq, mtr, md = mt.ratio_filter(i1, a, b, 0.75, device=local_rank)
-        be.h.profile()
+            return mt.ratio_filter(i1, a, b, 0.75, device=local_rank)
+        for _ in range(2):
+            mq, mtr, md = match_pass()
         barrier_sync()
         tm0 = time.perf_counter()
-        for _ in range(args.match_reps):
-            i1, i2, a, b = mt.knn2(q, t, "l2", device=local_rank)
-            mq, mtr, md = mt.ratio_filter(i1, a, b, 0.75, device=local_rank)
+        for _ in range(args.match_reps):          # timed without per-kernel events
+            mq, mtr, md = match_pass()
         barrier_sync()
         tm = max_over_ranks(time.perf_counter() - tm0)
-        mprof = be.h.profile()
-        be.h.set_profiling(False)
+        hd.set_profiling(True)
+        hd.profile()
+        for _ in range(args.match_reps):          # second pass for the kernel's own duration
+            match_pass()
+        mprof = hd.profile()
+        hd.set_profiling(False)
         pairs = float(n) * float(n) * args.match_reps
         knn_ms, knn_cnt = mprof["knn"]
         mroof = None
@@ -262,9 +316,12 @@ def main():
                                    "aligned residual order, Huber, SciPy-TRF control flow, fixed schedule",
                        "parallelism": f"points sharded over {world} rank(s), cameras replicated, RCCL all-reduce of [S|r]",
                        "seed": 1004},
-            "ba": {"damped_solves": n_solves, "trial_steps": n_trials, "cost_start": cost0, "cost_end": st.cost,
-                   "solves_per_s": n_solves / elapsed, "kernels": kernels},
-            "ba_cam_dim6": ba_d6, "roofline": roofline, "cpu_baseline": cpu_baseline, "matcher": matcher,
+            "ba": {"damped_solves": main["damped_solves"], "trial_steps": main["trial_steps"], "cost_start": main["cost_start"],
+                   "cost_end": main["cost_end"], "solves_per_s": main["damped_solves"] / elapsed, "kernels": kernels,
+                   "kernels_note": "HIP-event times from a second pass of the same schedule; the timed pass carries no events",
+                   "loop": "sfm_ba_trf_outer (library-side trust-region loop)"},
+            "ba_cam_dim6": ba_d6, "ba_mixed_precision": ba_mixed, "dropin": dropin,
+            "roofline": roofline, "rooflines": roofs, "cpu_baseline": cpu_baseline, "matcher": matcher,
             "driver_rows": driver_rows,
         }
         print(json.dumps(out), flush=True)

@@ -33,6 +33,8 @@ const char* sfm_last_error(sfm_handle h);
 int         sfm_set_stream(sfm_handle h, void* hip_stream);
 int         sfm_synchronize(sfm_handle h);
 const char* sfm_version(void);
+/* Stream-ordered copy of device memory the library owns (e.g. sfm_ba_get_structure) to the host; synchronises. */
+int         sfm_copy_to_host(sfm_handle h, void* dst_host, const void* src_device, int64_t bytes);
 
 /* Per-kernel device timing with HIP events recorded on the handle's stream (what bench.py's
  * roofline numbers are computed from).  Off by default.  sfm_profile_read synchronises the stream,
@@ -81,45 +83,64 @@ int sfm_match_f32_to_u8(sfm_handle h, const float* src, int64_t n_elems, uint8_t
 /* ------------------------------------------------------------------ bundle adjustment
  * Replaces what scipy.optimize.least_squares does for bundle_adjust: evaluation of the
  * closure `objective` (sfm_reconstruction.py:472-501), its Jacobian, the Huber scaling
- * (scipy _lsq/common.py:720-731) and the damped step (H + alpha I) p = -g of the exact
- * trust-region solver (scipy _lsq/common.py:57-168), done block-sparse with a Schur complement.
- * The trust-region state machine (scipy _lsq/trf.py:401-560) stays on the host (sfm_amd/trf.py)
- * and calls these stages; between stages it may all-reduce the regions named `reduce_*`
- * across ranks (points sharded over GPUs, cameras replicated).
+ * (scipy _lsq/common.py:720-731), the damped step (H + alpha I) p = -g of the exact
+ * trust-region solver (scipy _lsq/common.py:57-168), done block-sparse with a Schur complement,
+ * and the trust-region loop itself (scipy _lsq/trf.py:401-560): sfm_ba_run_trf is the single call
+ * that stands where `optimize.least_squares(...)` stands at sfm_reconstruction.py:506-514.
+ * The stages are exported too: a multi-rank host (points sharded over GPUs, cameras replicated)
+ * all-reduces the regions named `reduce_*` between them, either itself (sfm_amd/ba.py) or through
+ * the sfm_reduce_fn hook of the trust-region loop.
  *
  * Parameter vector x = [cams (n_cams*cam_dim) | pts (n_pts*3)] float64, camera block
  * [rvec(3), t(3), fx, fy, cx, cy] for cam_dim 10 (reference, :416-427) or [rvec, t] for 6.
  * Observations are in the reference's point-major order (:430-435): pt_idx non-decreasing.
  */
+
+/* What bundle_adjust packs before it calls SciPy (sfm_reconstruction.py:409-451) - nothing kernel-specific.
+ * cam_idx / pt_idx / uv may be host or device pointers; sfm_ba_create_problem copies them. */
+enum { SFM_BA_FP64 = 0,    /* every intermediate in float64 (default; the reference's arithmetic) */
+       SFM_BA_MIXED = 1 }; /* Jacobian rows and W L^-T stored in float32, all sums / S / the solve in float64 */
 typedef struct {
   int32_t n_cams, n_pts, cam_dim, apply_reg;   /* apply_reg: add the 4 regulariser rows per camera (:489-499); rank 0 only */
   int64_t n_obs;
   const int32_t* cam_idx;    /* [n_obs] */
   const int32_t* pt_idx;     /* [n_obs] non-decreasing */
   const double*  uv;         /* [n_obs*2] pixel each observation is compared with */
+  double fx0, fy0, cx0, cy0; /* pre-BA self.K (:492-497); intrinsics of every camera when cam_dim == 6 */
+  double width, height, reg_weight;
+  int32_t precision;         /* SFM_BA_FP64 | SFM_BA_MIXED */
+  int32_t reserved;
+} sfm_ba_desc;
+
+typedef struct sfm_ba_prob* sfm_ba_problem;    /* opaque; owns its index structure (device memory) */
+
+/* Validates the indices and builds, ON THE DEVICE, everything the kernels need besides the arrays above:
+ * per-point / per-camera observation lists, the camera-pair lists of the Schur complement and their split
+ * into work items (sfm_ba_structure shows them).  Synchronises the stream (sizes are data-dependent).
+ * SFM_ERR_ARG for out-of-range or non point-major indices. */
+int  sfm_ba_create_problem(sfm_handle h, const sfm_ba_desc* desc, sfm_ba_problem* out);
+void sfm_ba_destroy_problem(sfm_ba_problem p);
+
+/* The index structure as built (device pointers, int32), for inspection and tests; sfm_amd/structure.py is
+ * its host-side mirror and produces bit-identical arrays. */
+typedef struct {
+  int64_t n_obs, n_pairs, n_items, n_cchunks, xcd_max_items;
   const int32_t* pt_ptr;     /* [n_pts+1]  obs range of each point (track) */
   const int32_t* cam_ptr;    /* [n_cams+1] ranges into cam_obs */
   const int32_t* cam_obs;    /* [n_obs] observation ids grouped by camera, ascending inside a camera */
   const int32_t* blk_ptr;    /* [n_cams*(n_cams+1)/2 + 1] ranges into pair_k/pair_k2, block (c<=c2) at c*n_cams - c*(c-1)/2 + (c2-c) */
   const int32_t* pair_k;     /* [n_pairs] observation of camera c  on a shared track */
   const int32_t* pair_k2;    /* [n_pairs] observation of camera c2 on the same track */
-  int64_t n_pairs;
-  const int32_t* item_ptr;   /* [n_cams*(n_cams+1)/2 + 1] work items per block: each <= 256 consecutive pairs of ONE block */
+  const int32_t* item_ptr;   /* [n_blocks+1] work items per block: each <= 256 consecutive pairs of ONE block */
   const int32_t* item_beg;   /* [n_items] ranges into pair_k / pair_k2 */
   const int32_t* item_end;   /* [n_items] */
-  int64_t n_items;
   const int32_t* xcd_ptr;    /* [9]  item ids of block rows c = x (mod 8): xcd_items[xcd_ptr[x] .. xcd_ptr[x+1]) */
   const int32_t* xcd_items;  /* [n_items] (workgroup b of the Schur kernel serves group b % 8: XCD-local L2 reuse of G) */
-  int64_t xcd_max_items;     /* largest of the 8 groups */
   const int32_t* cch_ptr;    /* [n_cams+1] chunks per camera: each <= 256 consecutive entries of cam_obs of ONE camera */
   const int32_t* cch_beg;    /* [n_cchunks] ranges into cam_obs */
   const int32_t* cch_end;    /* [n_cchunks] */
-  int64_t n_cchunks;
-  double fx0, fy0, cx0, cy0; /* pre-BA self.K (:492-497); intrinsics of every camera when cam_dim == 6 */
-  double width, height, reg_weight;
-  void*   workspace;
-  int64_t workspace_bytes;
-} sfm_ba_problem;
+} sfm_ba_structure;
+int sfm_ba_get_structure(sfm_ba_problem p, sfm_ba_structure* out_host);
 
 /* Byte offsets into the workspace of the regions the host reads or all-reduces. */
 typedef struct {
@@ -145,35 +166,81 @@ enum { SFM_SC_COST = 0, SFM_SC_GNORM2 = 1, SFM_SC_GINF = 2, SFM_SC_PNORM2 = 3, S
        SFM_SC_JS2 = 5, SFM_SC_GTS = 6, SFM_SC_COST_NEW = 7, SFM_SC_SNORM2 = 8, SFM_SC_XNEW_NORM2 = 9,
        SFM_SC_CHOL_FAIL = 10, SFM_SC_HDIAG = 11 /* max diag(H) */, SFM_SC_COUNT = 16 };
 
-int sfm_ba_get_layout(int32_t n_cams, int32_t n_pts, int64_t n_obs, int32_t cam_dim, int64_t n_items,
-                      int64_t n_cchunks, sfm_ba_layout* out_host);
+/* Layout of the workspace of a problem.  The workspace (total_bytes, device memory) is the caller's: bind it
+ * before the first stage; workspace == NULL makes the library allocate (and own) one.  rec / recB / G hold
+ * float32 values when the problem was created with SFM_BA_MIXED (rec_stride etc. are in bytes). */
+int sfm_ba_get_layout(sfm_ba_problem p, sfm_ba_layout* out_host);
+int sfm_ba_bind_workspace(sfm_handle h, sfm_ba_problem p, void* workspace, int64_t workspace_bytes);
 
 /* cost(x) = 1/2 sum rho(f_i^2) (Huber, per scalar) -> partial into reduce_step[2] (this rank's observations). */
-int sfm_ba_cost(sfm_handle h, const sfm_ba_problem* p, const double* x);
+int sfm_ba_cost(sfm_handle h, sfm_ba_problem p, const double* x);
 /* per-observation reprojection error ||proj - uv||_2.  shared_k != 0: ONE shared K = (fx0,fy0,cx0,cy0)
  * for every camera (compute_reconstruction_stats, :582-631); shared_k == 0: each camera's own
  * intrinsics when cam_dim == 10 (the reprojection rows of `objective`, :478-486). */
-int sfm_ba_reproj_errors(sfm_handle h, const sfm_ba_problem* p, const double* x, int shared_k, double* err_out);
+int sfm_ba_reproj_errors(sfm_handle h, sfm_ba_problem p, const double* x, int shared_k, double* err_out);
+
+/* The same without a problem object (nothing but the three packed arrays is needed): what
+ * compute_reconstruction_stats (:582-631) computes per observation.  All pointers are device pointers; indices
+ * must be in range (the caller's responsibility: there is no structure pass here). */
+int sfm_reproj_errors(sfm_handle h, int32_t n_cams, int32_t cam_dim, int64_t n_obs, const int32_t* cam_idx,
+                      const int32_t* pt_idx, const double* uv, const double* x, double fx, double fy, double cx,
+                      double cy, int shared_k, double* err_out);
 
 /* Linearise at x: records, B, gc, Cp, gp, cost -> reduce_lin region (+ gmax). */
-int sfm_ba_linearize(sfm_handle h, const sfm_ba_problem* p, const double* x);
+int sfm_ba_linearize(sfm_handle h, sfm_ba_problem p, const double* x);
 /* After the host has (all-)reduced reduce_lin and gmax: scalars COST, GNORM2, GINF, HDIAG. */
-int sfm_ba_finish_linearize(sfm_handle h, const sfm_ba_problem* p);
+int sfm_ba_finish_linearize(sfm_handle h, sfm_ba_problem p);
 
 /* Damped solve in three stages around two reductions. */
-int sfm_ba_schur_build(sfm_handle h, const sfm_ba_problem* p, double alpha);          /* -> reduce_S (partial) */
+int sfm_ba_schur_build(sfm_handle h, sfm_ba_problem p, double alpha);          /* -> reduce_S (partial) */
 /* Multi-rank only: reduce_S (lower triangle + r) -> reduce_Sp before the all-reduce, and back after it. */
-int sfm_ba_pack_system(sfm_handle h, const sfm_ba_problem* p);
-int sfm_ba_unpack_system(sfm_handle h, const sfm_ba_problem* p);
-int sfm_ba_schur_solve(sfm_handle h, const sfm_ba_problem* p, double alpha, int want_q); /* chol, p_c, p_p; -> reduce_q (partial) */
-int sfm_ba_finish_solve(sfm_handle h, const sfm_ba_problem* p, int want_q);              /* scalars PNORM2 (and PQ) */
+int sfm_ba_pack_system(sfm_handle h, sfm_ba_problem p);
+int sfm_ba_unpack_system(sfm_handle h, sfm_ba_problem p);
+int sfm_ba_schur_solve(sfm_handle h, sfm_ba_problem p, double alpha, int want_q); /* chol, p_c, p_p; -> reduce_q (partial) */
+int sfm_ba_finish_solve(sfm_handle h, sfm_ba_problem p, int want_q);              /* scalars PNORM2 (and PQ) */
 
 /* s = scale * p;  x_new = x + s;  partial sums for the predicted reduction and cost(x_new) -> reduce_step. */
-int sfm_ba_step(sfm_handle h, const sfm_ba_problem* p, const double* x, double scale, double* x_new);
-int sfm_ba_finish_step(sfm_handle h, const sfm_ba_problem* p, const double* x, double scale, const double* x_new);
+int sfm_ba_step(sfm_handle h, sfm_ba_problem p, const double* x, double scale, double* x_new);
+int sfm_ba_finish_step(sfm_handle h, sfm_ba_problem p, const double* x, double scale, const double* x_new);
 
 /* Copy the SFM_SC_COUNT scalars to the host (synchronises the stream). */
-int sfm_ba_read_scalars(sfm_handle h, const sfm_ba_problem* p, double* out_host);
+int sfm_ba_read_scalars(sfm_handle h, sfm_ba_problem p, double* out_host);
+
+/* ---- the trust-region loop (scipy _lsq/trf.py:401-560 trf_no_bounds + common.py:57-168,222-248,705-717),
+ * control flow on the host, every data-parallel stage above on the device.  Same state machine as
+ * sfm_amd/trf.py (the host-language mirror the multi-rank CPU tests drive). */
+typedef struct {
+  double ftol, xtol, gtol;        /* the reference passes ftol = xtol = 1e-4 (:512-513); SciPy's default gtol = 1e-8 */
+  int32_t max_nfev;               /* 100 (:511) */
+  int32_t max_outer;              /* < 0: no limit; otherwise stop after this many outer iterations (fixed schedules) */
+  int32_t check_tolerances;       /* 0 turns the gtol / ftol / xtol tests off (throughput runs) */
+  int32_t reserved;
+} sfm_trf_options;
+typedef struct {
+  double cost, optimality;        /* 1/2 sum rho(f^2) and ||g||_inf at the returned x */
+  int32_t nfev, njev, status;     /* SciPy's counters and termination status (0: max_nfev, 1 gtol, 2 ftol, 3 xtol, 4 both) */
+  int32_t n_solves, n_outer, reserved;
+} sfm_trf_result;
+/* All-reduce `count` doubles at device pointer `data` (inside the bound workspace) in place across the ranks:
+ * op 0 = SUM, 1 = MAX.  Return 0 on success.  NULL = single rank. */
+typedef int (*sfm_reduce_fn)(void* user, void* data, int64_t count, int op);
+
+typedef struct sfm_trf_state_s* sfm_trf_state;
+/* x: [n_cams*cam_dim + 3*n_pts] device doubles, start point in, current iterate out (after every sfm_ba_trf_outer).
+ * x_norm_pts_only_local: nothing to set - with a reduce hook the point part of ||x|| is summed over the ranks. */
+int  sfm_ba_trf_begin(sfm_handle h, sfm_ba_problem p, double* x, const sfm_trf_options* opt,
+                      sfm_reduce_fn reduce, void* reduce_user, sfm_trf_state* out);
+/* One outer iteration: the trial steps of the current linearisation up to the accepted one, then the next
+ * linearisation.  *more = 0 once the loop has ended (status set, max_nfev or max_outer reached). */
+int  sfm_ba_trf_outer(sfm_trf_state st, int* more);
+int  sfm_ba_trf_result(sfm_trf_state st, sfm_trf_result* out);
+/* (alpha, Delta, ||step||, accepted) of every trial so far, 4 doubles each; returns the number of trials. */
+int  sfm_ba_trf_trace(sfm_trf_state st, double* out_host, int32_t capacity_trials);
+void sfm_ba_trf_end(sfm_trf_state st);
+/* begin + outer until done + result + end. SFM_ERR_NUMERIC when a damped system is not positive definite or a
+ * step is not finite (x then holds the last accepted iterate). */
+int  sfm_ba_run_trf(sfm_handle h, sfm_ba_problem p, double* x, const sfm_trf_options* opt,
+                    sfm_reduce_fn reduce, void* reduce_user, sfm_trf_result* out);
 
 /* Dense SPD helpers used by the solve, exported for tests: in-place lower Cholesky of a [n][n]
  * row-major matrix and solves with the factor.  fail_flag: device int32, set when a pivot <= 0. */

@@ -95,9 +95,12 @@ def ratio_filter(idx1, d1, d2, ratio=0.75):
 
 def match_features(desc1, desc2, ratio=0.75, metric="l2"):
     """Returns (queryIdx, trainIdx, distance) arrays in query order.
-    Nt < 2 makes the reference raise at :151; the restatement returns no matches."""
-    if np.asarray(desc2).shape[0] < 2 or np.asarray(desc1).shape[0] == 0:
+    No query or no train rows: knnMatch returns [] and so does the loop (:147-155).  Exactly one train row:
+    each knn row has one entry and the unpacking `for m, n in matches` (:151) raises ValueError."""
+    if np.asarray(desc2).shape[0] == 0 or np.asarray(desc1).shape[0] == 0:
         z = np.zeros(0, np.int32)
         return z, z.copy(), np.zeros(0, np.float32)
+    if np.asarray(desc2).shape[0] == 1:
+        raise ValueError("not enough values to unpack (expected 2, got 1)")
     idx1, _, d1, d2 = knn2(desc1, desc2, metric)
     return ratio_filter(idx1, d1, d2, ratio)

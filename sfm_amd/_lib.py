@@ -17,18 +17,37 @@ PROF_SLOTS = ("lin_obs", "lin_rest", "build_G", "schur", "chol", "trsv", "backsu
 i32, i64, f64, vp = C.c_int32, C.c_int64, C.c_double, C.c_void_p
 
 
-class BAProblem(C.Structure):
+PREC_FP64, PREC_MIXED = 0, 1
+
+
+class BADesc(C.Structure):
+    """sfm_ba_desc: the arrays bundle_adjust packs (sfm_reconstruction.py:409-451) and the options."""
     _fields_ = [("n_cams", i32), ("n_pts", i32), ("cam_dim", i32), ("apply_reg", i32),
                 ("n_obs", i64),
-                ("cam_idx", vp), ("pt_idx", vp), ("uv", vp), ("pt_ptr", vp), ("cam_ptr", vp),
-                ("cam_obs", vp), ("blk_ptr", vp), ("pair_k", vp), ("pair_k2", vp),
-                ("n_pairs", i64),
-                ("item_ptr", vp), ("item_beg", vp), ("item_end", vp), ("n_items", i64),
-                ("xcd_ptr", vp), ("xcd_items", vp), ("xcd_max_items", i64),
-                ("cch_ptr", vp), ("cch_beg", vp), ("cch_end", vp), ("n_cchunks", i64),
+                ("cam_idx", vp), ("pt_idx", vp), ("uv", vp),
                 ("fx0", f64), ("fy0", f64), ("cx0", f64), ("cy0", f64),
                 ("width", f64), ("height", f64), ("reg_weight", f64),
-                ("workspace", vp), ("workspace_bytes", i64)]
+                ("precision", i32), ("reserved", i32)]
+
+
+class BAStructureView(C.Structure):
+    """sfm_ba_structure: device pointers of the index structure a problem owns."""
+    _fields_ = ([(n, i64) for n in ("n_obs", "n_pairs", "n_items", "n_cchunks", "xcd_max_items")] +
+                [(n, vp) for n in ("pt_ptr", "cam_ptr", "cam_obs", "blk_ptr", "pair_k", "pair_k2", "item_ptr",
+                                   "item_beg", "item_end", "xcd_ptr", "xcd_items", "cch_ptr", "cch_beg", "cch_end")])
+
+
+class TRFOptions(C.Structure):
+    _fields_ = [("ftol", f64), ("xtol", f64), ("gtol", f64), ("max_nfev", i32), ("max_outer", i32),
+                ("check_tolerances", i32), ("reserved", i32)]
+
+
+class TRFResultC(C.Structure):
+    _fields_ = [("cost", f64), ("optimality", f64), ("nfev", i32), ("njev", i32), ("status", i32),
+                ("n_solves", i32), ("n_outer", i32), ("reserved", i32)]
+
+
+REDUCE_FN = C.CFUNCTYPE(C.c_int, vp, vp, i64, C.c_int)
 
 
 class BALayout(C.Structure):
@@ -53,19 +72,31 @@ SIGNATURES = {
     "sfm_match_knn2": (C.c_int, [vp, C.c_int, vp, i64, vp, i64, C.c_int, vp, vp, vp, vp, vp, i64]),
     "sfm_match_ratio": (C.c_int, [vp, i64, vp, vp, vp, f64, vp, vp, vp, vp, vp, i64]),
     "sfm_match_f32_to_u8": (C.c_int, [vp, vp, i64, vp, vp]),
-    "sfm_ba_get_layout": (C.c_int, [i32, i32, i64, i32, i64, i64, C.POINTER(BALayout)]),
-    "sfm_ba_cost": (C.c_int, [vp, C.POINTER(BAProblem), vp]),
-    "sfm_ba_reproj_errors": (C.c_int, [vp, C.POINTER(BAProblem), vp, C.c_int, vp]),
-    "sfm_ba_linearize": (C.c_int, [vp, C.POINTER(BAProblem), vp]),
-    "sfm_ba_finish_linearize": (C.c_int, [vp, C.POINTER(BAProblem)]),
-    "sfm_ba_schur_build": (C.c_int, [vp, C.POINTER(BAProblem), f64]),
-    "sfm_ba_pack_system": (C.c_int, [vp, C.POINTER(BAProblem)]),
-    "sfm_ba_unpack_system": (C.c_int, [vp, C.POINTER(BAProblem)]),
-    "sfm_ba_schur_solve": (C.c_int, [vp, C.POINTER(BAProblem), f64, C.c_int]),
-    "sfm_ba_finish_solve": (C.c_int, [vp, C.POINTER(BAProblem), C.c_int]),
-    "sfm_ba_step": (C.c_int, [vp, C.POINTER(BAProblem), vp, f64, vp]),
-    "sfm_ba_finish_step": (C.c_int, [vp, C.POINTER(BAProblem), vp, f64, vp]),
-    "sfm_ba_read_scalars": (C.c_int, [vp, C.POINTER(BAProblem), C.POINTER(f64)]),
+    "sfm_copy_to_host": (C.c_int, [vp, vp, vp, i64]),
+    "sfm_ba_create_problem": (C.c_int, [vp, C.POINTER(BADesc), C.POINTER(vp)]),
+    "sfm_ba_destroy_problem": (None, [vp]),
+    "sfm_ba_get_structure": (C.c_int, [vp, C.POINTER(BAStructureView)]),
+    "sfm_ba_get_layout": (C.c_int, [vp, C.POINTER(BALayout)]),
+    "sfm_ba_bind_workspace": (C.c_int, [vp, vp, vp, i64]),
+    "sfm_reproj_errors": (C.c_int, [vp, i32, i32, i64, vp, vp, vp, vp, f64, f64, f64, f64, C.c_int, vp]),
+    "sfm_ba_trf_begin": (C.c_int, [vp, vp, vp, C.POINTER(TRFOptions), REDUCE_FN, vp, C.POINTER(vp)]),
+    "sfm_ba_trf_outer": (C.c_int, [vp, C.POINTER(C.c_int)]),
+    "sfm_ba_trf_result": (C.c_int, [vp, C.POINTER(TRFResultC)]),
+    "sfm_ba_trf_trace": (C.c_int, [vp, vp, i32]),
+    "sfm_ba_trf_end": (None, [vp]),
+    "sfm_ba_run_trf": (C.c_int, [vp, vp, vp, C.POINTER(TRFOptions), REDUCE_FN, vp, C.POINTER(TRFResultC)]),
+    "sfm_ba_cost": (C.c_int, [vp, vp, vp]),
+    "sfm_ba_reproj_errors": (C.c_int, [vp, vp, vp, C.c_int, vp]),
+    "sfm_ba_linearize": (C.c_int, [vp, vp, vp]),
+    "sfm_ba_finish_linearize": (C.c_int, [vp, vp]),
+    "sfm_ba_schur_build": (C.c_int, [vp, vp, f64]),
+    "sfm_ba_pack_system": (C.c_int, [vp, vp]),
+    "sfm_ba_unpack_system": (C.c_int, [vp, vp]),
+    "sfm_ba_schur_solve": (C.c_int, [vp, vp, f64, C.c_int]),
+    "sfm_ba_finish_solve": (C.c_int, [vp, vp, C.c_int]),
+    "sfm_ba_step": (C.c_int, [vp, vp, vp, f64, vp]),
+    "sfm_ba_finish_step": (C.c_int, [vp, vp, vp, f64, vp]),
+    "sfm_ba_read_scalars": (C.c_int, [vp, vp, C.POINTER(f64)]),
     "sfm_dense_cholesky": (C.c_int, [vp, vp, i32, vp]),
     "sfm_dense_trsv": (C.c_int, [vp, vp, i32, vp, C.c_int]),
     "sfm_assoc_workspace_bytes": (C.c_int, [i64, C.POINTER(i64)]),
@@ -79,6 +110,10 @@ _lib = None
 
 class SfmError(RuntimeError):
     pass
+
+
+class SfmNumericError(SfmError):
+    """SFM_ERR_NUMERIC: a damped system was not positive definite, a solve stalled or a step was not finite."""
 
 
 def load():
@@ -120,7 +155,7 @@ class Handle:
     def check(self, rc, what):
         if rc != 0:
             msg = self.lib.sfm_last_error(self._h)
-            raise SfmError(f"{what} failed ({rc}): {msg.decode() if msg else ''}")
+            raise (SfmNumericError if rc == -4 else SfmError)(f"{what} failed ({rc}): {msg.decode() if msg else ''}")
 
     def call(self, name, *args):
         self.check(getattr(self.lib, name)(self._h, *args), name)

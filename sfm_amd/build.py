@@ -7,29 +7,54 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
-SRC = [os.path.join(HERE, "csrc", f) for f in ("ctx.hip", "ba.hip", "dense.hip", "match.hip", "driver.hip")]
-HDR = [os.path.join(HERE, "csrc", "common.h"), os.path.join(HERE, "csrc", "dense.h"), os.path.join(ROOT, "include", "sfm_amd.h")]
+SRC = [os.path.join(HERE, "csrc", f) for f in ("ctx.hip", "ba.hip", "problem.hip", "trf.hip", "dense.hip", "match.hip", "driver.hip")]
+HDR = [os.path.join(HERE, "csrc", f) for f in ("common.h", "dense.h", "ba_internal.h")] + [os.path.join(ROOT, "include", "sfm_amd.h")]
 LIB = os.path.join(HERE, "lib", "libsfm_amd.so")
 
 
-def needs_build():
-    if not os.path.exists(LIB):
+OBJ_DIR = os.path.join(HERE, "lib", "obj")
+
+
+def _obj(src):
+    return os.path.join(OBJ_DIR, os.path.splitext(os.path.basename(src))[0] + ".o")
+
+
+def _stale(target, deps):
+    if not os.path.exists(target):
         return True
-    t = os.path.getmtime(LIB)
-    return any(os.path.getmtime(p) > t for p in SRC + HDR)
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(p) > t for p in deps)
+
+
+def needs_build():
+    return _stale(LIB, SRC + HDR)
 
 
 def build(force=False, verbose=True):
+    """One object per source (compiled in parallel, only when stale), then one link."""
     if not force and not needs_build():
         return LIB
-    os.makedirs(os.path.dirname(LIB), exist_ok=True)
+    from concurrent.futures import ThreadPoolExecutor
+    os.makedirs(OBJ_DIR, exist_ok=True)
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     # -amdgpu-mfma-vgpr-form: MFMA results land in VGPRs (gfx950 has one unified register file); with the default
     # AGPR form every accumulator value costs a v_accvgpr_read before the VALU can use it - in the matcher that
     # was a quarter of all VALU work (profiles/r01_pmc_matcher.txt)
-    cmd = [hipcc, "-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-shared",
-           "-mllvm", "-amdgpu-mfma-vgpr-form",
-           "-I" + os.path.join(ROOT, "include"), "-o", LIB] + SRC
+    flags = ["-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-mllvm", "-amdgpu-mfma-vgpr-form",
+             "-I" + os.path.join(ROOT, "include")]
+
+    def compile_one(src):
+        obj = _obj(src)
+        if force or _stale(obj, [src] + HDR):
+            cmd = [hipcc] + flags + ["-c", src, "-o", obj]
+            if verbose:
+                print(" ".join(cmd), flush=True)
+            subprocess.run(cmd, check=True)
+        return obj
+
+    with ThreadPoolExecutor(max_workers=min(len(SRC), os.cpu_count() or 1)) as ex:
+        objs = list(ex.map(compile_one, SRC))
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.run(cmd, check=True)

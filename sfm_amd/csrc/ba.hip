@@ -8,10 +8,13 @@
 // Data layout in HBM (all inside the caller's workspace, see ba_layout()):
 //   recA   [N][2D]    per observation, point-major: Jc~ rows (2xD)
 //   recB   [N][8]     per observation: Jp~ rows (2x3), f~ (2)
-//   G      [N][3][D]  per observation, per alpha: W_k L_j^-T  (L_j L_j^T = C_j + alpha I)
+//   G      [N][GS]    per observation, per alpha: W_k L_j^-T as [3][D]  (L_j L_j^T = C_j + alpha I)
+// These three are the bulk of the traffic.  Their storage type T is double, or float in SFM_BA_MIXED (then a G
+// block is padded to GS = 32 / 20 floats so that it is a whole number of 16-byte chunks; D = 10: one 128-byte
+// line).  Every sum over them (B, C, g, S, the step) is accumulated in float64 in both modes.
 //   S | r  [(n+1)][n] reduced camera system with its right-hand side as a bordered row
 // Observations of one point (a track) are contiguous; cameras are reached through cam_obs.
-#include "dense.h"
+#include "ba_internal.h"
 
 typedef double v4d __attribute__((ext_vector_type(4)));
 
@@ -20,20 +23,17 @@ typedef double v4d __attribute__((ext_vector_type(4)));
 #define CAMPRE 16   // r[3] t[3] fx fy cx cy  a b a1 b1 (Rodrigues coefficients)  |r|^2 pad
 
 // ------------------------------------------------------------------------------------ layout
-struct Lay {   // offsets in doubles
-  int64_t recA, recB, campre, campre2, B, gc, Cp, gp, Linv, e, v, tmp3, G, red_lin, gmax, red_S, red_q,
-      red_step, pc, pp, y, tvec, scalars, part_obs, part_pt, part_x, cost_reg, regrec, dense, sch_part, cch_part, cbl_part, total;
-  int64_t nblk_obs, nblk_pt;
-};
-
-static Lay ba_layout(int64_t C, int64_t P, int64_t N, int64_t D, int64_t n_items, int64_t n_cchunks) {
+Lay ba_layout(int64_t C, int64_t P, int64_t N, int64_t D, int64_t n_items, int64_t n_cchunks, int precision) {
   Lay L;
   int64_t o = 0, n = C * D;
   auto take = [&](int64_t cnt) { int64_t r = o; o = align_up(o + cnt, 32); return r; };
+  // record arrays: float64, or float32 in mixed precision (sized in doubles either way)
+  const int64_t es = precision == SFM_BA_MIXED ? 4 : 8;
+  auto take_rec = [&](int64_t elems) { return take((elems * es + 7) / 8); };
   L.nblk_obs = (N + 255) / 256;
   L.nblk_pt = (P + 255) / 256;
-  L.recA = take(N * 2 * D);
-  L.recB = take(N * 8);
+  L.recA = take_rec(N * 2 * D);
+  L.recB = take_rec(N * 8);
   L.campre = take(C * CAMPRE);
   L.campre2 = take(C * CAMPRE);
   L.B = take(C * D * D);
@@ -44,7 +44,7 @@ static Lay ba_layout(int64_t C, int64_t P, int64_t N, int64_t D, int64_t n_items
   L.e = take(P * 3);
   L.v = take(P * 3);
   L.tmp3 = take(N * 3);
-  L.G = take(N * 3 * D);
+  L.G = take_rec(N * ba_g_stride((int)D, precision));
   L.red_lin = take(2 * n + 2);
   L.gmax = take(2);
   L.red_S = take(n * n + n);
@@ -68,14 +68,13 @@ static Lay ba_layout(int64_t C, int64_t P, int64_t N, int64_t D, int64_t n_items
   return L;
 }
 
-extern "C" int sfm_ba_get_layout(int32_t n_cams, int32_t n_pts, int64_t n_obs, int32_t cam_dim, int64_t n_items,
-                                 int64_t n_cchunks, sfm_ba_layout* out) {
-  if (!out || n_cams < 1 || n_pts < 0 || n_obs < 0 || (cam_dim != 6 && cam_dim != 10) || n_items < 0 || n_cchunks < 0)
-    return SFM_ERR_ARG;
-  Lay L = ba_layout(n_cams, n_pts, n_obs, cam_dim, n_items, n_cchunks);
-  int64_t n = (int64_t)n_cams * cam_dim;
+extern "C" int sfm_ba_get_layout(sfm_ba_problem p, sfm_ba_layout* out) {
+  if (!p || !out) return SFM_ERR_ARG;
+  const Lay& L = p->L;
+  const int64_t n = (int64_t)p->n_cams * p->cam_dim;
+  const int64_t es = p->precision == SFM_BA_MIXED ? 4 : 8;
   out->total_bytes = L.total * 8;
-  out->rec_off = L.recA * 8; out->rec_stride = 2 * cam_dim * 8;
+  out->rec_off = L.recA * 8; out->rec_stride = 2 * p->cam_dim * es;
   out->recB_off = L.recB * 8;
   out->B_off = L.B * 8; out->gc_off = L.gc * 8;
   out->Cp_off = L.Cp * 8; out->gp_off = L.gp * 8;
@@ -195,13 +194,13 @@ __device__ __forceinline__ void cam_project(const double* __restrict__ cp, doubl
 // 2x(D+3) Jacobian, Huber row scaling.  The two record arrays are transposed through
 // LDS one after the other (43 KB instead of 59 KB: 3 workgroups per CU) so the doubles of 256 observations
 // leave the CU as contiguous, fully coalesced streams.
-template <int D>
+template <int D, typename T>
 __global__ __launch_bounds__(256) void k_lin_obs(int64_t N, const int* __restrict__ cam_idx,
                                                  const int* __restrict__ pt_idx,
                                                  const double* __restrict__ uv,
                                                  const double* __restrict__ pts,
                                                  const double* __restrict__ campre,
-                                                 double* __restrict__ recA, double* __restrict__ recB,
+                                                 T* __restrict__ recA, T* __restrict__ recB,
                                                  double* __restrict__ part) {
   constexpr int WA = 2 * D, LDA = WA + 1, WB = 8, LDB = WB + 1;
   __shared__ double s_rec[256 * LDA];
@@ -270,10 +269,10 @@ __global__ __launch_bounds__(256) void k_lin_obs(int64_t N, const int* __restric
   if (tid == 0) part[blockIdx.x] = tot;
   const int nvalid = (int)((N - k0) < 256 ? (N - k0) : 256);
   {
-    double* outp = recA + (size_t)k0 * WA;
+    T* outp = recA + (size_t)k0 * WA;
     for (int i = tid; i < nvalid * WA; i += 256) {
       const int t = i / WA, q = i - t * WA;
-      outp[i] = s_rec[t * LDA + q];
+      outp[i] = (T)s_rec[t * LDA + q];
     }
   }
   __syncthreads();
@@ -284,18 +283,19 @@ __global__ __launch_bounds__(256) void k_lin_obs(int64_t N, const int* __restric
   }
   __syncthreads();
   {
-    double* outp = recB + (size_t)k0 * WB;
+    T* outp = recB + (size_t)k0 * WB;
     for (int i = tid; i < nvalid * WB; i += 256) {
       const int t = i >> 3, q = i & 7;
-      outp[i] = s_rec[t * LDB + q];
+      outp[i] = (T)s_rec[t * LDB + q];
     }
   }
 }
 
 // per point: C_j = sum Jp~^T Jp~ (packed xx,xy,xz,yy,yz,zz), g_pj = sum Jp~^T f~ ; block partials of
 // ||g_p||^2 and max|g_p|.
+template <typename T>
 __global__ __launch_bounds__(256) void k_point_blocks(int P, const int* __restrict__ pt_ptr,
-                                                      const double* __restrict__ recB,
+                                                      const T* __restrict__ recB,
                                                       double* __restrict__ Cp, double* __restrict__ gp,
                                                       double* __restrict__ part) {
   __shared__ double s_red[4];
@@ -304,7 +304,7 @@ __global__ __launch_bounds__(256) void k_point_blocks(int P, const int* __restri
   if (j < P) {
     double c0 = 0, c1 = 0, c2 = 0, c3 = 0, c4 = 0, c5 = 0, g0 = 0, g1 = 0, g2v = 0;
     for (int k = pt_ptr[j]; k < pt_ptr[j + 1]; ++k) {
-      const double* r = recB + (size_t)k * 8;
+      const T* r = recB + (size_t)k * 8;
       const double a0 = r[0], a1 = r[1], a2 = r[2], b0 = r[3], b1 = r[4], b2 = r[5], f0 = r[6], f1 = r[7];
       c0 += a0 * a0 + b0 * b0; c1 += a0 * a1 + b0 * b1; c2 += a0 * a2 + b0 * b2;
       c3 += a1 * a1 + b1 * b1; c4 += a1 * a2 + b1 * b2; c5 += a2 * a2 + b2 * b2;
@@ -326,11 +326,11 @@ __global__ __launch_bounds__(256) void k_point_blocks(int P, const int* __restri
 // per camera: B_c = sum Jc~^T Jc~ (DxD), g_c = sum Jc~^T f~ over the camera's observations.
 // One workgroup per chunk of <= 256 observations of one camera: the chunk's Jc~ rows and f~ are gathered into
 // LDS and contracted on the matrix cores; the chunks of a camera are added in fixed order (k_cam_blocks_final).
-template <int D>
+template <int D, typename T>
 __global__ __launch_bounds__(256) void k_cam_blocks_chunks(const int* __restrict__ cch_beg, const int* __restrict__ cch_end,
                                                            const int* __restrict__ cam_obs,
-                                                           const double* __restrict__ recA,
-                                                           const double* __restrict__ recB, double* __restrict__ part) {
+                                                           const T* __restrict__ recA,
+                                                           const T* __restrict__ recB, double* __restrict__ part) {
   // [B | g] = M^T M restricted to rows < D, with M = [Jc~ | f~] (2 rows per observation, D + 1 columns): one 16x16
   // tile of v_mfma_f64_16x16x4_f64 per wavefront, K = (observation, residual row), both operands the same LDS rows.
   // Each wavefront takes a quarter of the chunk; the four partial tiles are added in fixed order.
@@ -342,7 +342,7 @@ __global__ __launch_bounds__(256) void k_cam_blocks_chunks(const int* __restrict
   for (int i = tid; i < cnt * W; i += 256) {
     const int o = i / W, q = i - o * W;
     const int k = cam_obs[beg + o];
-    s[o * LDW + q] = (q < 2 * D) ? recA[(size_t)k * (2 * D) + q] : recB[(size_t)k * 8 + 6 + (q - 2 * D)];
+    s[o * LDW + q] = (q < 2 * D) ? (double)recA[(size_t)k * (2 * D) + q] : (double)recB[(size_t)k * 8 + 6 + (q - 2 * D)];
   }
   __syncthreads();
   const int col = lane & 15, kq = lane >> 4;             // operand column (0..D-1: Jc~, D: f~), k slot
@@ -499,24 +499,25 @@ __global__ void k_point_factor(int P, double alpha, const double* __restrict__ C
 // G_k[m][a] = sum_r Jc~[r][a] * V[r][m],  V = Jp~ M^T (2x3).  16 lanes per observation (a = lane & 15 < D),
 // each lane produces the three m entries of its column: Jc~ reads and G writes are contiguous over a, the
 // 12 doubles of Jp~ and M are the same address for the whole group (one request per group).
-template <int D>
+template <int D, typename T, int GS>
 __global__ __launch_bounds__(256) void k_build_G(int64_t N, const int* __restrict__ pt_idx,
-                                                 const double* __restrict__ recA, const double* __restrict__ recB,
-                                                 const double* __restrict__ Linv, double* __restrict__ G) {
+                                                 const T* __restrict__ recA, const T* __restrict__ recB,
+                                                 const double* __restrict__ Linv, T* __restrict__ G) {
   const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
   const int64_t k = t >> 4;
   const int a = (int)(t & 15);
   if (k >= N || a >= D) return;
-  const double* r = recA + (size_t)k * (2 * D);
+  const T* r = recA + (size_t)k * (2 * D);
   const double* M = Linv + (size_t)pt_idx[k] * 6;
-  const double* jp = recB + (size_t)k * 8;
+  const T* jp = recB + (size_t)k * 8;
   const double j0 = jp[0], j1 = jp[1], j2 = jp[2], j3 = jp[3], j4 = jp[4], j5 = jp[5];
   const double m00 = M[0], m10 = M[1], m11 = M[2], m20 = M[3], m21 = M[4], m22 = M[5];
   const double c0 = r[a], c1 = r[D + a];
-  double* g = G + (size_t)k * (3 * D) + a;
-  g[0] = c0 * (j0 * m00) + c1 * (j3 * m00);
-  g[D] = c0 * (j0 * m10 + j1 * m11) + c1 * (j3 * m10 + j4 * m11);
-  g[2 * D] = c0 * (j0 * m20 + j1 * m21 + j2 * m22) + c1 * (j3 * m20 + j4 * m21 + j5 * m22);
+  T* g = G + (size_t)k * GS + a;
+  g[0] = (T)(c0 * (j0 * m00) + c1 * (j3 * m00));
+  g[D] = (T)(c0 * (j0 * m10 + j1 * m11) + c1 * (j3 * m10 + j4 * m11));
+  g[2 * D] = (T)(c0 * (j0 * m20 + j1 * m21 + j2 * m22) + c1 * (j3 * m20 + j4 * m21 + j5 * m22));
+  if (GS > 3 * D && a < GS - 3 * D) g[3 * D] = (T)0;     // padding of the block (read as part of a 16-byte chunk, never used)
 }
 
 // Reduced camera system  S[c][c2] = [c == c2] B_c - sum_{(k,k2) on a shared track} G_k G_k2^T  (c <= c2, mirrored).
@@ -526,23 +527,26 @@ __global__ __launch_bounds__(256) void k_build_G(int64_t N, const int* __restric
 // row = (l>>4) + 4*reg.  Pair ids are loaded 64 at a time (coalesced) and broadcast with v_readlane so the
 // 16 gathers of 8 pairs are in flight together.  k_schur_assemble then sums the items of each block in
 // order (bitwise reproducible), adds B_c on the diagonal and writes the block and its mirror.
-template <int D>
+template <int D, typename T, int GS>
 __global__ __launch_bounds__(256) void k_schur_items(const int* __restrict__ xcd_ptr, const int* __restrict__ xcd_items,
                                                      const int* __restrict__ item_beg,
                                                      const int* __restrict__ item_end,
                                                      const int* __restrict__ pair_k, const int* __restrict__ pair_k2,
-                                                     const double* __restrict__ G, double* __restrict__ part) {
+                                                     const T* __restrict__ G, double* __restrict__ part) {
   // Gathers are latency-bound (about 5 us under load), so what counts is useful bytes in flight per register:
-  // a G block is 3 D doubles = CH 16-byte chunks, one lane fetches one chunk (global_load_dwordx4) and one
-  // instruction fetches BPL whole blocks (D = 10: 4 blocks on 60 lanes, D = 6: 7 on 63) - twice the bytes per
-  // VGPR of a one-double-per-lane gather that only 30 of 64 lanes take part in.  The blocks then pass through a
-  // wave-private LDS slab to reach the MFMA operand layout (lane = (row, m)).
-  constexpr int BLK = 3 * D;                   // doubles per G block
-  constexpr int CH = BLK / 2;                  // 16-byte chunks per block
+  // a G block is BB bytes = CH 16-byte chunks, one lane fetches one chunk (global_load_dwordx4) and one
+  // instruction fetches BPL whole blocks (float64 D = 10: 4 blocks on 60 lanes, D = 6: 7 on 63; float32 D = 10:
+  // 8 blocks = 8 full 128-byte lines on 64 lanes, D = 6: 12 on 60) - at least twice the bytes per VGPR of a
+  // one-element-per-lane gather that only 30 of 64 lanes take part in.  The blocks then pass through a
+  // wave-private LDS slab to reach the MFMA operand layout (lane = (row, m)), widened to float64 there.
+  typedef int chunk_t __attribute__((ext_vector_type(4)));
+  constexpr int BB = GS * (int)sizeof(T);      // bytes per G block
+  static_assert(BB % 16 == 0, "a G block must be a whole number of 16-byte chunks");
+  constexpr int CH = BB / 16;                  // 16-byte chunks per block
   constexpr int BPL = 64 / CH;                 // blocks per load instruction
-  constexpr int U = 8;                         // load instructions in flight per operand (16 costs occupancy: measured slower)
+  constexpr int U = (64 + BPL - 1) / BPL < 8 ? (64 + BPL - 1) / BPL : 8;   // load instructions in flight per operand (16 costs occupancy: measured slower)
   constexpr int PB = U * BPL;                  // pairs per batch
-  __shared__ double s_stage[4][2][BPL * BLK];
+  __shared__ __attribute__((aligned(16))) char s_stage[4][2][BPL * BB];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   // workgroup b serves item group b % 8 (block rows c = b % 8 mod 8): with the round-robin XCD placement one
   // XCD sees every item of a camera's block row, so that camera's G blocks (1.2 MB at 5,000 observations) are
@@ -557,8 +561,9 @@ __global__ __launch_bounds__(256) void k_schur_items(const int* __restrict__ xcd
   const int off = valid ? m * D + row : 0;
   const int lb = lane / CH, lc = lane - lb * CH;          // this lane's block / chunk within a load
   const bool loader = lb < BPL;
-  double* sA = s_stage[w][0];
-  double* sB = s_stage[w][1];
+  char* sA = s_stage[w][0];
+  char* sB = s_stage[w][1];
+  const char* Gb = (const char*)G;
   v4d acc = {0.0, 0.0, 0.0, 0.0};
   for (int base = beg; base < end; base += 64) {
     const int idx = base + lane;
@@ -566,29 +571,29 @@ __global__ __launch_bounds__(256) void k_schur_items(const int* __restrict__ xcd
     const int kk2 = idx < end ? pair_k2[idx] : 0;
     const int cnt = (end - base) < 64 ? (end - base) : 64;
     for (int u0 = 0; u0 < cnt; u0 += PB) {
-      double2 ra[U], rb[U];
+      chunk_t ra[U], rb[U];
 #pragma unroll
       for (int t = 0; t < U; ++t) {
         const int p = u0 + t * BPL + lb;                  // pair this lane fetches a chunk of
         const int k = __shfl(kk, p & 63, 64), k2 = __shfl(kk2, p & 63, 64);
         const bool ok = loader && p < cnt;
-        ra[t] = ok ? *(const double2*)(G + (size_t)k * BLK + 2 * lc) : make_double2(0.0, 0.0);
-        rb[t] = ok ? *(const double2*)(G + (size_t)k2 * BLK + 2 * lc) : make_double2(0.0, 0.0);
+        ra[t] = ok ? *(const chunk_t*)(Gb + (size_t)k * BB + 16 * lc) : (chunk_t){0, 0, 0, 0};
+        rb[t] = ok ? *(const chunk_t*)(Gb + (size_t)k2 * BB + 16 * lc) : (chunk_t){0, 0, 0, 0};
       }
 #pragma unroll
       for (int t = 0; t < U; ++t) {
         if (u0 + t * BPL >= cnt) break;                   // wave-uniform
         if (loader) {
-          *(double2*)(sA + lb * BLK + 2 * lc) = ra[t];
-          *(double2*)(sB + lb * BLK + 2 * lc) = rb[t];
+          *(chunk_t*)(sA + lb * BB + 16 * lc) = ra[t];
+          *(chunk_t*)(sB + lb * BB + 16 * lc) = rb[t];
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 #pragma unroll
         for (int bb = 0; bb < BPL; ++bb) {
           if (u0 + t * BPL + bb >= cnt) break;            // wave-uniform
-          const double a = valid ? sA[bb * BLK + off] : 0.0;
-          const double b = valid ? sB[bb * BLK + off] : 0.0;
+          const double a = valid ? (double)((const T*)sA)[bb * GS + off] : 0.0;
+          const double b = valid ? (double)((const T*)sB)[bb * GS + off] : 0.0;
           acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");     // the slab is rewritten by the next t
@@ -628,10 +633,10 @@ __global__ __launch_bounds__(256) void k_schur_assemble(int C, const int* __rest
 // out[c][a] = (base ? base[c][a] : 0) - sum_{k in camera c} sum_m G_k[m][a] vec[pt(k)][m]
 // Camera lists are cut into chunks of <= 256 observations: one workgroup per chunk (16 observation slots x
 // 16 lanes over a), slots reduced through LDS in fixed order; k_cam_reduce_final sums a camera's chunks in order.
-template <int D>
+template <int D, typename T, int GS>
 __global__ __launch_bounds__(256) void k_cam_reduce_chunks(const int* __restrict__ cch_beg, const int* __restrict__ cch_end,
                                                            const int* __restrict__ cam_obs, const int* __restrict__ pt_idx,
-                                                           const double* __restrict__ G, const double* __restrict__ vec,
+                                                           const T* __restrict__ G, const double* __restrict__ vec,
                                                            double* __restrict__ part) {
   __shared__ double s[16 * 16];
   const int ch = blockIdx.x, tid = threadIdx.x;
@@ -640,9 +645,9 @@ __global__ __launch_bounds__(256) void k_cam_reduce_chunks(const int* __restrict
   if (a < D) {
     for (int i = cch_beg[ch] + slot; i < cch_end[ch]; i += 16) {
       const int k = cam_obs[i];
-      const double* g = G + (size_t)k * (3 * D) + a;
+      const T* g = G + (size_t)k * GS + a;
       const double* v = vec + (size_t)pt_idx[k] * 3;
-      acc += g[0] * v[0] + g[D] * v[1] + g[2 * D] * v[2];
+      acc += (double)g[0] * v[0] + (double)g[D] * v[1] + (double)g[2 * D] * v[2];
     }
   }
   s[slot * 16 + a] = acc;
@@ -666,18 +671,18 @@ __global__ void k_cam_reduce_final(int C, const int* __restrict__ cch_ptr, const
 }
 
 // tmp3[k][m] = sum_a G_k[m][a] p_c[cam(k)][a]
-template <int D>
+template <int D, typename T, int GS>
 __global__ __launch_bounds__(256) void k_obs_Gtp(int64_t total, const int* __restrict__ cam_idx,
-                                                 const double* __restrict__ G,
+                                                 const T* __restrict__ G,
                                                  const double* __restrict__ pc, double* __restrict__ tmp3) {
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= total) return;
   const int64_t k = i / 3;
-  const double* g = G + (size_t)i * D;
+  const T* g = G + (size_t)k * GS + (size_t)(i - 3 * k) * D;
   const double* p = pc + (size_t)cam_idx[k] * D;
   double t = 0.0;
 #pragma unroll
-  for (int a = 0; a < D; ++a) t += g[a] * p[a];
+  for (int a = 0; a < D; ++a) t += (double)g[a] * p[a];
   tmp3[i] = t;
 }
 
@@ -750,9 +755,13 @@ __global__ __launch_bounds__(256) void k_finish_solve(int n, const double* __res
   double at = block_sum256(a, s_red);
   double bt = block_sum256(b, s_red);
   if (threadIdx.x == 0) {
-    sc[SFM_SC_PNORM2] = at + red_q[n];
-    sc[SFM_SC_PQ] = want_q ? (bt + red_q[n + 1]) : 0.0;
-    sc[SFM_SC_CHOL_FAIL] = (double)(*flag);
+    const double pn2 = at + red_q[n], pq = want_q ? (bt + red_q[n + 1]) : 0.0;
+    sc[SFM_SC_PNORM2] = pn2;
+    sc[SFM_SC_PQ] = pq;
+    // 1: non-positive pivot, 2: a triangular solve stalled, 3: the step is not finite (NaN/Inf in the system)
+    int f = *flag;
+    if (f == 0 && !(isfinite(pn2) && isfinite(pq))) f = 3;
+    sc[SFM_SC_CHOL_FAIL] = (double)f;
   }
 }
 
@@ -777,10 +786,10 @@ __global__ __launch_bounds__(256) void k_axpy_step(int64_t n_c, int64_t n_total,
 }
 
 // per observation: (J~ s) for both rows -> partial sums of (J~ s)^2 and f~ (J~ s)
-template <int D>
+template <int D, typename T>
 __global__ __launch_bounds__(256) void k_step_obs(int64_t N, const int* __restrict__ cam_idx,
                                                   const int* __restrict__ pt_idx,
-                                                  const double* __restrict__ recA, const double* __restrict__ recB,
+                                                  const T* __restrict__ recA, const T* __restrict__ recB,
                                                   const double* __restrict__ pc, const double* __restrict__ pp,
                                                   double scale, double* __restrict__ part) {
   __shared__ double s_red[4];
@@ -789,17 +798,17 @@ __global__ __launch_bounds__(256) void k_step_obs(int64_t N, const int* __restri
   if (i < 2 * N) {
     const int64_t k = i >> 1;
     const int row = (int)(i & 1);
-    const double* jc = recA + (size_t)k * (2 * D) + row * D;
-    const double* rb = recB + (size_t)k * 8;
-    const double* jp = rb + row * 3;
+    const T* jc = recA + (size_t)k * (2 * D) + row * D;
+    const T* rb = recB + (size_t)k * 8;
+    const T* jp = rb + row * 3;
     const double* c = pc + (size_t)cam_idx[k] * D;
     const double* q = pp + (size_t)pt_idx[k] * 3;
-    double t = jp[0] * q[0] + jp[1] * q[1] + jp[2] * q[2];
+    double t = (double)jp[0] * q[0] + (double)jp[1] * q[1] + (double)jp[2] * q[2];
 #pragma unroll
-    for (int a = 0; a < D; ++a) t += jc[a] * c[a];
+    for (int a = 0; a < D; ++a) t += (double)jc[a] * c[a];
     t *= scale;
     j2 = t * t;
-    gt = rb[6 + row] * t;
+    gt = (double)rb[6 + row] * t;
   }
   double a = block_sum256(j2, s_red);
   double b = block_sum256(gt, s_red);
@@ -903,17 +912,11 @@ __global__ __launch_bounds__(256) void k_finish_step(int n_c, const double* __re
 }
 
 // ------------------------------------------------------------------------------------ host stages
-static int check_problem(sfm_ctx* h, const sfm_ba_problem* p, Lay* L) {
+static int check_problem(sfm_ctx* h, sfm_ba_problem p, Lay* L) {
   if (!h) return SFM_ERR_ARG;
-  if (!p || p->n_cams < 1 || p->n_pts < 1 || p->n_obs < 1 || (p->cam_dim != 6 && p->cam_dim != 10))
-    return sfm_fail(h, SFM_ERR_ARG, "sfm_ba", "bad problem sizes / cam_dim");
-  if (!p->cam_idx || !p->pt_idx || !p->uv || !p->pt_ptr || !p->cam_ptr || !p->cam_obs || !p->blk_ptr ||
-      (p->n_pairs > 0 && (!p->pair_k || !p->pair_k2)) || !p->item_ptr || !p->item_beg || !p->item_end ||
-      !p->cch_ptr || !p->cch_beg || !p->cch_end || !p->xcd_ptr || !p->xcd_items || p->xcd_max_items < 0 || !p->workspace)
-    return sfm_fail(h, SFM_ERR_ARG, "sfm_ba", "null pointer in problem");
-  if ((int64_t)p->n_cams * p->cam_dim > 32000) return sfm_fail(h, SFM_ERR_ARG, "sfm_ba", "reduced system too large");
-  *L = ba_layout(p->n_cams, p->n_pts, p->n_obs, p->cam_dim, p->n_items, p->n_cchunks);
-  if (p->workspace_bytes < L->total * 8) return sfm_fail(h, SFM_ERR_WORKSPACE, "sfm_ba", "workspace too small");
+  if (!p) return sfm_fail(h, SFM_ERR_ARG, "sfm_ba", "null problem");
+  if (!p->workspace) return sfm_fail(h, SFM_ERR_WORKSPACE, "sfm_ba", "no workspace bound (sfm_ba_bind_workspace)");
+  *L = p->L;
   return SFM_OK;
 }
 
@@ -923,8 +926,20 @@ static int check_problem(sfm_ctx* h, const sfm_ba_problem* p, Lay* L) {
     if ((D) == 10) { constexpr int DD = 10; __VA_ARGS__; } \
     else { constexpr int DD = 6; __VA_ARGS__; }            \
   } while (0)
+// camera block width DD, storage type TT of the record arrays, G block stride GG (elements)
+#define DISPATCH_DT(D, PREC, ...)                                                                     \
+  do {                                                                                                \
+    if ((PREC) == SFM_BA_MIXED) {                                                                     \
+      if ((D) == 10) { constexpr int DD = 10; constexpr int GG = 32; typedef float TT; __VA_ARGS__; } \
+      else { constexpr int DD = 6; constexpr int GG = 20; typedef float TT; __VA_ARGS__; }            \
+    } else {                                                                                          \
+      if ((D) == 10) { constexpr int DD = 10; constexpr int GG = 30; typedef double TT; __VA_ARGS__; } \
+      else { constexpr int DD = 6; constexpr int GG = 18; typedef double TT; __VA_ARGS__; }           \
+    }                                                                                                 \
+  } while (0)
+#define WST(L, field) ((TT*)(ws + (L).field))
 
-static int launch_cost(sfm_ctx* h, const sfm_ba_problem* p, const Lay& L, double* ws, const double* x,
+static int launch_cost(sfm_ctx* h, sfm_ba_problem p, const Lay& L, double* ws, const double* x,
                        const double* pc_for_reg, double scale, int with_lin, double* err_out) {
   const int C = p->n_cams, D = p->cam_dim;
   const int64_t N = p->n_obs;
@@ -942,7 +957,7 @@ static int launch_cost(sfm_ctx* h, const sfm_ba_problem* p, const Lay& L, double
   return SFM_OK;
 }
 
-extern "C" int sfm_ba_cost(sfm_handle h, const sfm_ba_problem* p, const double* x) {
+extern "C" int sfm_ba_cost(sfm_handle h, sfm_ba_problem p, const double* x) {
   Lay L; int rc = check_problem(h, p, &L); if (rc) return rc;
   double* ws = (double*)p->workspace;
   rc = launch_cost(h, p, L, ws, x, nullptr, 0.0, 0, nullptr); if (rc) return rc;
@@ -960,7 +975,7 @@ __global__ void k_set_intrinsics(int C, double fx, double fy, double cx, double 
   o[6] = fx; o[7] = fy; o[8] = cx; o[9] = cy;
 }
 
-extern "C" int sfm_ba_reproj_errors(sfm_handle h, const sfm_ba_problem* p, const double* x, int shared_k,
+extern "C" int sfm_ba_reproj_errors(sfm_handle h, sfm_ba_problem p, const double* x, int shared_k,
                                     double* err_out) {
   Lay L; int rc = check_problem(h, p, &L); if (rc) return rc;
   if (!err_out) return sfm_fail(h, SFM_ERR_ARG, "sfm_ba_reproj_errors", "null output");
@@ -978,24 +993,43 @@ extern "C" int sfm_ba_reproj_errors(sfm_handle h, const sfm_ba_problem* p, const
   return SFM_OK;
 }
 
-extern "C" int sfm_ba_linearize(sfm_handle h, const sfm_ba_problem* p, const double* x) {
+extern "C" int sfm_reproj_errors(sfm_handle h, int32_t n_cams, int32_t cam_dim, int64_t n_obs, const int32_t* cam_idx,
+                                 const int32_t* pt_idx, const double* uv, const double* x, double fx, double fy, double cx,
+                                 double cy, int shared_k, double* err_out) {
+  if (!h) return SFM_ERR_ARG;
+  if (n_cams < 1 || n_obs < 1 || (cam_dim != 6 && cam_dim != 10) || !cam_idx || !pt_idx || !uv || !x || !err_out)
+    return sfm_fail(h, SFM_ERR_ARG, "sfm_reproj_errors", "bad argument");
+  double* campre = (double*)sfm_scratch(h, (size_t)n_cams * CAMPRE * sizeof(double));
+  if (!campre) return sfm_fail(h, SFM_ERR_HIP, "sfm_reproj_errors", "scratch allocation failed");
+  const int C = n_cams;
+  DISPATCH_D(cam_dim, hipLaunchKernelGGL(k_campre<DD>, dim3(cdiv(C, 64)), dim3(64), 0, h->stream, x, C, fx, fy, cx, cy, campre));
+  if (shared_k)
+    hipLaunchKernelGGL(k_set_intrinsics, dim3(cdiv(C, 64)), dim3(64), 0, h->stream, C, fx, fy, cx, cy, campre);
+  hipLaunchKernelGGL(k_cost_obs, dim3(cdiv(n_obs, 256)), dim3(256), 0, h->stream, n_obs, cam_idx, pt_idx, uv,
+                     x + (size_t)C * cam_dim, campre, (double*)nullptr, 0, 0, err_out);
+  SFM_LAUNCH_CHECK(h, "sfm_reproj_errors");
+  return SFM_OK;
+}
+
+extern "C" int sfm_ba_linearize(sfm_handle h, sfm_ba_problem p, const double* x) {
   Lay L; int rc = check_problem(h, p, &L); if (rc) return rc;
   double* ws = (double*)p->workspace;
   const int C = p->n_cams, P = p->n_pts, D = p->cam_dim, n = C * D;
   const int64_t N = p->n_obs;
   const double* pts = x + (size_t)n;
-  DISPATCH_D(D, {
+  DISPATCH_DT(D, p->precision, {
     hipLaunchKernelGGL(k_campre<DD>, dim3(cdiv(C, 64)), dim3(64), 0, h->stream, x, C, p->fx0, p->fy0, p->cx0,
                        p->cy0, WS(L, campre));
     sfm_prof_begin(h, SFM_PROF_LIN_OBS);
-    hipLaunchKernelGGL(k_lin_obs<DD>, dim3((unsigned)L.nblk_obs), dim3(256), 0, h->stream, N, p->cam_idx,
-                       p->pt_idx, p->uv, pts, WS(L, campre), WS(L, recA), WS(L, recB), WS(L, part_obs));
+    hipLaunchKernelGGL((k_lin_obs<DD, TT>), dim3((unsigned)L.nblk_obs), dim3(256), 0, h->stream, N, p->cam_idx,
+                       p->pt_idx, p->uv, pts, WS(L, campre), WST(L, recA), WST(L, recB), WS(L, part_obs));
     sfm_prof_end(h, SFM_PROF_LIN_OBS);
     sfm_prof_begin(h, SFM_PROF_LIN_REST);
-    hipLaunchKernelGGL(k_point_blocks, dim3((unsigned)L.nblk_pt), dim3(256), 0, h->stream, P, p->pt_ptr,
-                       WS(L, recB), WS(L, Cp), WS(L, gp), WS(L, part_pt));
-    hipLaunchKernelGGL(k_cam_blocks_chunks<DD>, dim3((unsigned)p->n_cchunks), dim3(256), 0, h->stream, p->cch_beg,
-                       p->cch_end, p->cam_obs, WS(L, recA), WS(L, recB), WS(L, cbl_part));
+    hipLaunchKernelGGL(k_point_blocks<TT>, dim3((unsigned)L.nblk_pt), dim3(256), 0, h->stream, P, p->pt_ptr,
+                       WST(L, recB), WS(L, Cp), WS(L, gp), WS(L, part_pt));
+    if (p->n_cchunks > 0)
+      hipLaunchKernelGGL((k_cam_blocks_chunks<DD, TT>), dim3((unsigned)p->n_cchunks), dim3(256), 0, h->stream, p->cch_beg,
+                         p->cch_end, p->cam_obs, WST(L, recA), WST(L, recB), WS(L, cbl_part));
     hipLaunchKernelGGL(k_cam_blocks_final<DD>, dim3(cdiv((int64_t)C * (DD * DD + DD), 256)), dim3(256), 0, h->stream, C,
                        p->cch_ptr, WS(L, cbl_part), WS(L, B), WS(L, gc));
   });
@@ -1014,7 +1048,7 @@ extern "C" int sfm_ba_linearize(sfm_handle h, const sfm_ba_problem* p, const dou
   return SFM_OK;
 }
 
-extern "C" int sfm_ba_finish_linearize(sfm_handle h, const sfm_ba_problem* p) {
+extern "C" int sfm_ba_finish_linearize(sfm_handle h, sfm_ba_problem p) {
   Lay L; int rc = check_problem(h, p, &L); if (rc) return rc;
   double* ws = (double*)p->workspace;
   hipLaunchKernelGGL(k_finish_linearize, dim3(1), dim3(256), 0, h->stream, p->n_cams * p->cam_dim,
@@ -1023,7 +1057,7 @@ extern "C" int sfm_ba_finish_linearize(sfm_handle h, const sfm_ba_problem* p) {
   return SFM_OK;
 }
 
-extern "C" int sfm_ba_schur_build(sfm_handle h, const sfm_ba_problem* p, double alpha) {
+extern "C" int sfm_ba_schur_build(sfm_handle h, sfm_ba_problem p, double alpha) {
   Lay L; int rc = check_problem(h, p, &L); if (rc) return rc;
   if (!(alpha > 0.0)) return sfm_fail(h, SFM_ERR_ARG, "sfm_ba_schur_build", "alpha must be > 0");
   double* ws = (double*)p->workspace;
@@ -1032,18 +1066,19 @@ extern "C" int sfm_ba_schur_build(sfm_handle h, const sfm_ba_problem* p, double 
   sfm_prof_begin(h, SFM_PROF_BUILD_G);
   hipLaunchKernelGGL(k_point_factor, dim3(cdiv(P, 256)), dim3(256), 0, h->stream, P, alpha, WS(L, Cp), WS(L, gp),
                      WS(L, Linv), WS(L, e));
-  DISPATCH_D(D, {
-    hipLaunchKernelGGL(k_build_G<DD>, dim3(cdiv(N * 16, 256)), dim3(256), 0, h->stream, N, p->pt_idx, WS(L, recA),
-                       WS(L, recB), WS(L, Linv), WS(L, G));
+  DISPATCH_DT(D, p->precision, {
+    hipLaunchKernelGGL((k_build_G<DD, TT, GG>), dim3(cdiv(N * 16, 256)), dim3(256), 0, h->stream, N, p->pt_idx, WST(L, recA),
+                       WST(L, recB), WS(L, Linv), WST(L, G));
     sfm_prof_end(h, SFM_PROF_BUILD_G);
     sfm_prof_begin(h, SFM_PROF_SCHUR);
     if (p->n_items > 0)   // 8 groups x ceil(largest group / 4) workgroups
-      hipLaunchKernelGGL(k_schur_items<DD>, dim3(8 * cdiv(p->xcd_max_items, 4)), dim3(256), 0, h->stream,
-                         p->xcd_ptr, p->xcd_items, p->item_beg, p->item_end, p->pair_k, p->pair_k2, WS(L, G), WS(L, sch_part));
+      hipLaunchKernelGGL((k_schur_items<DD, TT, GG>), dim3(8 * cdiv(p->xcd_max_items, 4)), dim3(256), 0, h->stream,
+                         p->xcd_ptr, p->xcd_items, p->item_beg, p->item_end, p->pair_k, p->pair_k2, WST(L, G), WS(L, sch_part));
     hipLaunchKernelGGL(k_schur_assemble<DD>, dim3(C, cdiv(C, 2)), dim3(256), 0, h->stream, C, p->item_ptr,
                        WS(L, sch_part), WS(L, B), WS(L, red_S));
-    hipLaunchKernelGGL(k_cam_reduce_chunks<DD>, dim3((unsigned)p->n_cchunks), dim3(256), 0, h->stream, p->cch_beg,
-                       p->cch_end, p->cam_obs, p->pt_idx, WS(L, G), WS(L, e), WS(L, cch_part));
+    if (p->n_cchunks > 0)
+      hipLaunchKernelGGL((k_cam_reduce_chunks<DD, TT, GG>), dim3((unsigned)p->n_cchunks), dim3(256), 0, h->stream, p->cch_beg,
+                         p->cch_end, p->cam_obs, p->pt_idx, WST(L, G), WS(L, e), WS(L, cch_part));
     hipLaunchKernelGGL(k_cam_reduce_final<DD>, dim3(cdiv(n, 256)), dim3(256), 0, h->stream, C, p->cch_ptr,
                        WS(L, cch_part), WS(L, gc), WS(L, red_S) + (size_t)n * n);
     sfm_prof_end(h, SFM_PROF_SCHUR);
@@ -1064,7 +1099,7 @@ __global__ __launch_bounds__(256) void k_pack_lower(const double* __restrict__ S
   }
 }
 
-static int pack_S(sfm_handle h, const sfm_ba_problem* p, int unpack_dir, const char* what) {
+static int pack_S(sfm_handle h, sfm_ba_problem p, int unpack_dir, const char* what) {
   Lay L; int rc = check_problem(h, p, &L); if (rc) return rc;
   double* ws = (double*)p->workspace;
   const int n = p->n_cams * p->cam_dim;
@@ -1073,10 +1108,10 @@ static int pack_S(sfm_handle h, const sfm_ba_problem* p, int unpack_dir, const c
   SFM_LAUNCH_CHECK(h, what);
   return SFM_OK;
 }
-extern "C" int sfm_ba_pack_system(sfm_handle h, const sfm_ba_problem* p) { return pack_S(h, p, 0, "sfm_ba_pack_system"); }
-extern "C" int sfm_ba_unpack_system(sfm_handle h, const sfm_ba_problem* p) { return pack_S(h, p, 1, "sfm_ba_unpack_system"); }
+extern "C" int sfm_ba_pack_system(sfm_handle h, sfm_ba_problem p) { return pack_S(h, p, 0, "sfm_ba_pack_system"); }
+extern "C" int sfm_ba_unpack_system(sfm_handle h, sfm_ba_problem p) { return pack_S(h, p, 1, "sfm_ba_unpack_system"); }
 
-extern "C" int sfm_ba_schur_solve(sfm_handle h, const sfm_ba_problem* p, double alpha, int want_q) {
+extern "C" int sfm_ba_schur_solve(sfm_handle h, sfm_ba_problem p, double alpha, int want_q) {
   Lay L; int rc = check_problem(h, p, &L); if (rc) return rc;
   double* ws = (double*)p->workspace;
   const int C = p->n_cams, P = p->n_pts, D = p->cam_dim, n = C * D;
@@ -1094,16 +1129,17 @@ extern "C" int sfm_ba_schur_solve(sfm_handle h, const sfm_ba_problem* p, double 
   rc = dense_trsv(h, n, dw, WS(L, tvec), WS(L, pc), 1); if (rc) return rc;
   sfm_prof_end(h, SFM_PROF_TRSV);
   sfm_prof_begin(h, SFM_PROF_BACKSUB);
-  DISPATCH_D(D, hipLaunchKernelGGL(k_obs_Gtp<DD>, dim3(cdiv(N * 3, 256)), dim3(256), 0, h->stream, N * 3,
-                                   p->cam_idx, WS(L, G), WS(L, pc), WS(L, tmp3)));
+  DISPATCH_DT(D, p->precision, hipLaunchKernelGGL((k_obs_Gtp<DD, TT, GG>), dim3(cdiv(N * 3, 256)), dim3(256), 0, h->stream, N * 3,
+                                                  p->cam_idx, WST(L, G), WS(L, pc), WS(L, tmp3)));
   hipLaunchKernelGGL(k_backsub, dim3((unsigned)L.nblk_pt), dim3(256), 0, h->stream, P, p->pt_ptr, WS(L, tmp3),
                      WS(L, Linv), WS(L, e), WS(L, pp), WS(L, v), WS(L, part_pt));
   hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(256), 0, h->stream, WS(L, part_pt), (int)L.nblk_pt, 2,
                      WS(L, red_q) + n);
   if (want_q) {
-    DISPATCH_D(D, {
-      hipLaunchKernelGGL(k_cam_reduce_chunks<DD>, dim3((unsigned)p->n_cchunks), dim3(256), 0, h->stream, p->cch_beg,
-                         p->cch_end, p->cam_obs, p->pt_idx, WS(L, G), WS(L, v), WS(L, cch_part));
+    DISPATCH_DT(D, p->precision, {
+      if (p->n_cchunks > 0)
+        hipLaunchKernelGGL((k_cam_reduce_chunks<DD, TT, GG>), dim3((unsigned)p->n_cchunks), dim3(256), 0, h->stream, p->cch_beg,
+                           p->cch_end, p->cam_obs, p->pt_idx, WST(L, G), WS(L, v), WS(L, cch_part));
       hipLaunchKernelGGL(k_cam_reduce_final<DD>, dim3(cdiv(n, 256)), dim3(256), 0, h->stream, C, p->cch_ptr,
                          WS(L, cch_part), (const double*)nullptr, WS(L, red_q));
     });
@@ -1113,7 +1149,7 @@ extern "C" int sfm_ba_schur_solve(sfm_handle h, const sfm_ba_problem* p, double 
   return SFM_OK;
 }
 
-extern "C" int sfm_ba_finish_solve(sfm_handle h, const sfm_ba_problem* p, int want_q) {
+extern "C" int sfm_ba_finish_solve(sfm_handle h, sfm_ba_problem p, int want_q) {
   Lay L; int rc = check_problem(h, p, &L); if (rc) return rc;
   double* ws = (double*)p->workspace;
   const int n = p->n_cams * p->cam_dim;
@@ -1131,7 +1167,7 @@ extern "C" int sfm_ba_finish_solve(sfm_handle h, const sfm_ba_problem* p, int wa
   return SFM_OK;
 }
 
-extern "C" int sfm_ba_step(sfm_handle h, const sfm_ba_problem* p, const double* x, double scale, double* x_new) {
+extern "C" int sfm_ba_step(sfm_handle h, sfm_ba_problem p, const double* x, double scale, double* x_new) {
   Lay L; int rc = check_problem(h, p, &L); if (rc) return rc;
   double* ws = (double*)p->workspace;
   const int C = p->n_cams, P = p->n_pts, D = p->cam_dim, n = C * D;
@@ -1141,8 +1177,8 @@ extern "C" int sfm_ba_step(sfm_handle h, const sfm_ba_problem* p, const double* 
   const unsigned nblk_x = cdiv(ntot, 256), nblk_rows = cdiv(2 * N, 256);
   hipLaunchKernelGGL(k_axpy_step, dim3(nblk_x), dim3(256), 0, h->stream, (int64_t)n, ntot, x, WS(L, pc), WS(L, pp),
                      scale, x_new, part_x);
-  DISPATCH_D(D, hipLaunchKernelGGL(k_step_obs<DD>, dim3(nblk_rows), dim3(256), 0, h->stream, N, p->cam_idx,
-                                   p->pt_idx, WS(L, recA), WS(L, recB), WS(L, pc), WS(L, pp), scale, WS(L, part_obs)));
+  DISPATCH_DT(D, p->precision, hipLaunchKernelGGL((k_step_obs<DD, TT>), dim3(nblk_rows), dim3(256), 0, h->stream, N, p->cam_idx,
+                                                  p->pt_idx, WST(L, recA), WST(L, recB), WS(L, pc), WS(L, pp), scale, WS(L, part_obs)));
   rc = launch_cost(h, p, L, ws, x_new, WS(L, pc), scale, 1, nullptr); if (rc) return rc;
   const int nreg = (D == 10 && p->apply_reg) ? C : 0;
   hipLaunchKernelGGL(k_step_finalize, dim3(1), dim3(256), 0, h->stream, WS(L, part_obs), (int)L.nblk_obs,
@@ -1152,7 +1188,7 @@ extern "C" int sfm_ba_step(sfm_handle h, const sfm_ba_problem* p, const double* 
   return SFM_OK;
 }
 
-extern "C" int sfm_ba_finish_step(sfm_handle h, const sfm_ba_problem* p, const double* x, double scale,
+extern "C" int sfm_ba_finish_step(sfm_handle h, sfm_ba_problem p, const double* x, double scale,
                                   const double* x_new) {
   Lay L; int rc = check_problem(h, p, &L); if (rc) return rc;
   double* ws = (double*)p->workspace;
@@ -1163,7 +1199,41 @@ extern "C" int sfm_ba_finish_step(sfm_handle h, const sfm_ba_problem* p, const d
   return SFM_OK;
 }
 
-extern "C" int sfm_ba_read_scalars(sfm_handle h, const sfm_ba_problem* p, double* out_host) {
+// ---- ||x||^2 for the trust-region loop's initial radius (Delta_0 = ||x_0||, scipy trf.py:422-430)
+__global__ __launch_bounds__(256) void k_sq_partials(int64_t n, const double* __restrict__ v, double* __restrict__ part) {
+  __shared__ double s_red[4];
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const double t = i < n ? v[i] * v[i] : 0.0;
+  const double a = block_sum256(t, s_red);
+  if (threadIdx.x == 0) part[blockIdx.x] = a;
+}
+__global__ __launch_bounds__(256) void k_xnorm_finish(int n_c, const double* __restrict__ x, const double* __restrict__ red_step,
+                                                      double* __restrict__ sc) {
+  __shared__ double s_red[4];
+  double a = 0.0;
+  for (int i = threadIdx.x; i < n_c; i += 256) a += x[i] * x[i];
+  const double t = block_sum256(a, s_red);
+  if (threadIdx.x == 0) sc[SFM_SC_XNEW_NORM2] = t + red_step[4];
+}
+int ba_xnorm_partial(sfm_ctx* h, sfm_ba_problem p, const double* x) {
+  Lay L; int rc = check_problem(h, p, &L); if (rc) return rc;
+  double* ws = (double*)p->workspace;
+  const int64_t n = (int64_t)p->n_cams * p->cam_dim, np3 = 3 * (int64_t)p->n_pts;
+  const unsigned nb = cdiv(np3, 256);       // part_x holds ((n + 3P + 255) / 256) * 2 + 2 doubles: enough
+  hipLaunchKernelGGL(k_sq_partials, dim3(nb), dim3(256), 0, h->stream, np3, x + n, WS(L, part_x));
+  hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(256), 0, h->stream, WS(L, part_x), (int)nb, 1, WS(L, red_step) + 4);
+  SFM_LAUNCH_CHECK(h, "ba_xnorm_partial");
+  return SFM_OK;
+}
+int ba_xnorm_finish(sfm_ctx* h, sfm_ba_problem p, const double* x) {
+  Lay L; int rc = check_problem(h, p, &L); if (rc) return rc;
+  double* ws = (double*)p->workspace;
+  hipLaunchKernelGGL(k_xnorm_finish, dim3(1), dim3(256), 0, h->stream, p->n_cams * p->cam_dim, x, WS(L, red_step), WS(L, scalars));
+  SFM_LAUNCH_CHECK(h, "ba_xnorm_finish");
+  return SFM_OK;
+}
+
+extern "C" int sfm_ba_read_scalars(sfm_handle h, sfm_ba_problem p, double* out_host) {
   Lay L; int rc = check_problem(h, p, &L); if (rc) return rc;
   double* ws = (double*)p->workspace;
   SFM_HIP(h, hipMemcpyAsync(h->pinned, WS(L, scalars), SFM_SC_COUNT * sizeof(double), hipMemcpyDeviceToHost, h->stream));

@@ -21,6 +21,8 @@ struct sfm_ctx {
   double* pinned;          // SFM_SC_COUNT doubles of pinned host memory for scalar read-back
   int profiling;
   sfm_prof_slot prof[SFM_PROF_COUNT];
+  void* scratch;           // growable device scratch for calls that take no workspace (sfm_scratch)
+  size_t scratch_bytes;
 };
 
 // HIP-event bracket around one kernel (or one short kernel sequence) on the handle's stream.

@@ -1,5 +1,5 @@
 // Handle management for libsfm_amd.so.
-#include "common.h"
+#include "ba_internal.h"
 
 extern "C" const char* sfm_version(void) { return "sfm_amd 0.1 (gfx950)"; }
 
@@ -21,6 +21,8 @@ extern "C" int sfm_create(int device, sfm_handle* out) {
   h->err[0] = 0;
   h->pinned = nullptr;
   h->profiling = 0;
+  h->scratch = nullptr;
+  h->scratch_bytes = 0;
   memset(h->prof, 0, sizeof(h->prof));
   if ((e = hipHostMalloc((void**)&h->pinned, SFM_SC_COUNT * sizeof(double), hipHostMallocDefault)) != hipSuccess) {
     fprintf(stderr, "sfm_create: hipHostMalloc -> %s\n", hipGetErrorString(e));
@@ -29,6 +31,19 @@ extern "C" int sfm_create(int device, sfm_handle* out) {
   }
   *out = h;
   return SFM_OK;
+}
+
+// Device scratch owned by the handle: grown (never shrunk) on demand.  Growing synchronises the stream first, so
+// work already enqueued that still uses the old buffer has finished before it is freed.
+void* sfm_scratch(sfm_ctx* h, size_t bytes) {
+  if (bytes <= h->scratch_bytes) return h->scratch;
+  (void)hipStreamSynchronize(h->stream);
+  if (h->scratch) (void)hipFree(h->scratch);
+  h->scratch = nullptr; h->scratch_bytes = 0;
+  const size_t want = (bytes + (1u << 20) - 1) & ~(size_t)((1u << 20) - 1);
+  if (hipMalloc(&h->scratch, want) != hipSuccess) { h->scratch = nullptr; return nullptr; }
+  h->scratch_bytes = want;
+  return h->scratch;
 }
 
 void sfm_prof_fold(sfm_ctx* h, int slot) {
@@ -75,6 +90,7 @@ extern "C" void sfm_destroy(sfm_handle h) {
         (void)hipEventDestroy(h->prof[k].stop[i]);
       }
   if (h->pinned) (void)hipHostFree(h->pinned);
+  if (h->scratch) (void)hipFree(h->scratch);
   delete h;
 }
 
@@ -88,6 +104,14 @@ extern "C" int sfm_set_stream(sfm_handle h, void* hip_stream) {
 
 extern "C" int sfm_synchronize(sfm_handle h) {
   if (!h) return SFM_ERR_ARG;
+  SFM_HIP(h, hipStreamSynchronize(h->stream));
+  return SFM_OK;
+}
+
+extern "C" int sfm_copy_to_host(sfm_handle h, void* dst_host, const void* src_device, int64_t bytes) {
+  if (!h) return SFM_ERR_ARG;
+  if (!dst_host || !src_device || bytes < 0) return sfm_fail(h, SFM_ERR_ARG, "sfm_copy_to_host", "bad argument");
+  SFM_HIP(h, hipMemcpyAsync(dst_host, src_device, (size_t)bytes, hipMemcpyDeviceToHost, h->stream));
   SFM_HIP(h, hipStreamSynchronize(h->stream));
   return SFM_OK;
 }

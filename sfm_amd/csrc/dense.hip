@@ -805,7 +805,8 @@ __device__ __forceinline__ bool trsv_pending(double v) { return __double_as_long
 template <bool TRANSPOSE>
 __global__ __launch_bounds__(256) void k_trsv_flow(const double* __restrict__ L, const double* __restrict__ LT, int n,
                                                    const double* __restrict__ Dinv, const double* __restrict__ DinvT,
-                                                   const double* __restrict__ b, double* __restrict__ xout) {
+                                                   const double* __restrict__ b, double* __restrict__ xout,
+                                                   int* __restrict__ fail) {
   __shared__ double sM[128 * 128];
   __shared__ double sacc[128], sx[128], shalf[128];
   const int tid = threadIdx.x;
@@ -853,10 +854,12 @@ __global__ __launch_bounds__(256) void k_trsv_flow(const double* __restrict__ L,
       double v = 0.0;
       if (tid < nbb) {
         // bounded: a producer that never publishes (it cannot, by construction) must not hang the device -
-        // after ~4 s the element is taken as it is (an all-ones NaN) and the caller sees a non-finite solution
+        // after ~4 s the element is taken as it is (an all-ones NaN), the failure flag is raised (value 2) and the
+        // caller gets SFM_ERR_NUMERIC / a raised SfmError instead of a silently non-finite step
         int spins = 0;
         do { v = __hip_atomic_load(&xout[rb + tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
         while (trsv_pending(v) && ++spins < (1 << 22));
+        if (trsv_pending(v)) *fail = 2;
       }
       sx[tid] = v;
     }
@@ -936,9 +939,9 @@ int dense_trsv(sfm_ctx* h, int n, const DenseWs& w, double* b, double* xout, int
     if (hipMemsetAsync(xout, 0xFF, (size_t)n * sizeof(double), h->stream) != hipSuccess)     // "not published yet"
       return sfm_fail(h, SFM_ERR_HIP, "dense_trsv", "memset");
     if (transpose)
-      hipLaunchKernelGGL(k_trsv_flow<true>, dim3(8 * nblk), dim3(256), 0, h->stream, L, w.LmT, n, w.Dinv, w.DinvT, b, xout);
+      hipLaunchKernelGGL(k_trsv_flow<true>, dim3(8 * nblk), dim3(256), 0, h->stream, L, w.LmT, n, w.Dinv, w.DinvT, b, xout, w.flag);
     else
-      hipLaunchKernelGGL(k_trsv_flow<false>, dim3(8 * nblk), dim3(256), 0, h->stream, L, w.LmT, n, w.Dinv, w.DinvT, b, xout);
+      hipLaunchKernelGGL(k_trsv_flow<false>, dim3(8 * nblk), dim3(256), 0, h->stream, L, w.LmT, n, w.Dinv, w.DinvT, b, xout, w.flag);
     SFM_LAUNCH_CHECK(h, "dense_trsv");
     return SFM_OK;
   }
@@ -987,7 +990,8 @@ extern "C" int sfm_dense_trsv(sfm_handle h, const double* l, int32_t n, double* 
   if (!h || !l || !b || n < 1) return SFM_ERR_ARG;
   double* base = nullptr;
   SFM_HIP(h, hipMalloc(&base, ((size_t)dense_ws_doubles(n) + n) * sizeof(double)));
-  DenseWs w; dense_ws_carve(base, n, &w);
+  DenseWs w; dense_ws_carve(base, n, &w);          // w.flag points into the workspace
+  SFM_HIP(h, hipMemsetAsync(w.flag, 0, sizeof(int), h->stream));
   double* xout = base + dense_ws_doubles(n);
   SFM_HIP(h, hipMemcpyAsync(w.Lm, l, (size_t)n * n * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
   hipLaunchKernelGGL(k_transpose_copy, dim3(cdiv((int64_t)n * n, 256)), dim3(256), 0, h->stream, l, n, w.LmT);

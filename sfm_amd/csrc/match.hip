@@ -11,7 +11,12 @@
 // the query on the lane and 16 train rows in the registers, so the running top-2 of a query never
 // leaves its lane).  Candidates are ranked by ONE int32 key = ((TN_i + 2 dot) << 8) | row-in-chunk,
 // i.e. v_lshl_add_u32 + v_min_i32 + v_med3_i32 per candidate; keys are unpacked every 128 train rows.
-// Ties go to the lower train index (OpenCV's documented order); sqrtf is applied once at the end.
+// Ranking rule = the reference's: OpenCV compares the float32 distances sqrtf(d^2), lowest train index first
+// on ties (matcher_oracle.py).  sqrtf is monotone and injective on integers below 2^22, so ranking on the integer
+// d^2 gives the same two neighbours whenever the second-best d^2 is below 2^22 (always, for SIFT descriptors:
+// rows of norm <= 512 are at most 2^20 apart).  From 2^22 on distinct d^2 can round to the same float32 and the
+// lower index must win among them; queries whose second-best d^2 reaches 2^22 are therefore re-ranked on the
+// float32 value over the whole train set by k_knn2_u8_rerank (k_merge_splits_u8 lists them).
 #include "common.h"
 #include <cstdlib>
 
@@ -214,8 +219,8 @@ __global__ __launch_bounds__(256) void k_knn2_u8(const uint8_t* __restrict__ q, 
     const int64_t qi = q0 + qb * 32 + l31;
     if (half == 0 && qi < nq) {
       Cand* o = part + ((int64_t)split * nq + qi) * 2;
-      o[0].d = b1i >= 0 ? sqrt_rn_f32(b1d) : 0.0f; o[0].i = b1i;
-      o[1].d = b2i >= 0 ? sqrt_rn_f32(b2d) : 0.0f; o[1].i = b2i;
+      o[0].d = b1i >= 0 ? b1d : 0.0f; o[0].i = b1i;      // d = d^2 (an exact integer below 2^24); k_merge_splits_u8 takes the root
+      o[1].d = b2i >= 0 ? b2d : 0.0f; o[1].i = b2i;
     }
   }
 }
@@ -289,6 +294,71 @@ __global__ __launch_bounds__(256) void k_merge_splits(int64_t nq, int nsplit, co
   idx1[qi] = b1i; idx2[qi] = b2i; d1[qi] = b1d; d2[qi] = b2d;
 }
 
+// L2 / uint8: the per-split candidates carry the exact integer d^2 (as float32).  Merge by (d^2, index), take the
+// correctly rounded float32 root, and list the queries whose second neighbour lies where sqrtf stops being
+// injective (d^2 >= 2^22): those are re-ranked on the float32 value by k_knn2_u8_rerank.
+#define D2_SQRT_INJECTIVE_BELOW 4194304.0f
+__global__ __launch_bounds__(256) void k_merge_splits_u8(int64_t nq, int nsplit, const Cand* __restrict__ part,
+                                                         int* __restrict__ idx1, int* __restrict__ idx2,
+                                                         float* __restrict__ d1, float* __restrict__ d2,
+                                                         int* __restrict__ fix_cnt, int* __restrict__ fix_list) {
+  const int64_t qi = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (qi >= nq) return;
+  float b1d = 3.0e38f, b2d = 3.0e38f; int b1i = -1, b2i = -1;
+  for (int s = 0; s < nsplit; ++s) {
+    const Cand* c = part + ((int64_t)s * nq + qi) * 2;
+    top2_insert(c[0].d, c[0].i, b1d, b1i, b2d, b2i);
+    top2_insert(c[1].d, c[1].i, b1d, b1i, b2d, b2i);
+  }
+  idx1[qi] = b1i; idx2[qi] = b2i; d1[qi] = sqrt_rn_f32(b1d); d2[qi] = sqrt_rn_f32(b2d);
+  if (b2d >= D2_SQRT_INJECTIVE_BELOW) fix_list[atomicAdd(fix_cnt, 1)] = (int)qi;     // list order is irrelevant: one writer per query
+}
+
+// One workgroup per listed query (grid-stride over the list, whose length is only known on the device): every
+// train row's exact integer d^2, its float32 root, top-2 by (root, index) - the rule of the oracle - over the
+// whole train set.  Rare by construction (see the header), so it is written for clarity, not speed.
+__global__ __launch_bounds__(256) void k_knn2_u8_rerank(const uint8_t* __restrict__ q, const uint8_t* __restrict__ t,
+                                                        int64_t nt, int dim, const int* __restrict__ fix_cnt,
+                                                        const int* __restrict__ fix_list, int* __restrict__ idx1,
+                                                        int* __restrict__ idx2, float* __restrict__ d1,
+                                                        float* __restrict__ d2) {
+  __shared__ uint32_t s_q[32];
+  __shared__ Cand s_c[256][2];
+  const int tid = threadIdx.x;
+  const int n_fix = *fix_cnt;
+  const int words = dim >> 2;
+  for (int f = blockIdx.x; f < n_fix; f += gridDim.x) {
+    const int qi = fix_list[f];
+    __syncthreads();
+    if (tid < words) s_q[tid] = ((const uint32_t*)(q + (int64_t)qi * dim))[tid];
+    __syncthreads();
+    float b1d = 3.0e38f, b2d = 3.0e38f; int b1i = -1, b2i = -1;
+    for (int64_t r = tid; r < nt; r += 256) {
+      const uint32_t* tr = (const uint32_t*)(t + r * dim);
+      int d2i = 0;
+      for (int k = 0; k < words; ++k) {
+        const uint32_t a = s_q[k], b = tr[k];
+#pragma unroll
+        for (int sft = 0; sft < 32; sft += 8) {
+          const int df = (int)((a >> sft) & 0xFFu) - (int)((b >> sft) & 0xFFu);
+          d2i += df * df;
+        }
+      }
+      top2_insert(sqrt_rn_f32((float)d2i), (int)r, b1d, b1i, b2d, b2i);
+    }
+    s_c[tid][0].d = b1d; s_c[tid][0].i = b1i; s_c[tid][1].d = b2d; s_c[tid][1].i = b2i;
+    __syncthreads();
+    if (tid == 0) {
+      float m1d = 3.0e38f, m2d = 3.0e38f; int m1i = -1, m2i = -1;
+      for (int u = 0; u < 256; ++u) {
+        top2_insert(s_c[u][0].d, s_c[u][0].i, m1d, m1i, m2d, m2i);
+        top2_insert(s_c[u][1].d, s_c[u][1].i, m1d, m1i, m2d, m2i);
+      }
+      idx1[qi] = m1i; idx2[qi] = m2i; d1[qi] = m1d; d2[qi] = m2d;
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------------ ratio test + compaction
 __global__ __launch_bounds__(256) void k_ratio_count(int64_t nq, const float* __restrict__ d1,
                                                      const float* __restrict__ d2, double ratio,
@@ -351,6 +421,7 @@ extern "C" int sfm_match_workspace_bytes(int metric, int64_t nq, int64_t nt, int
   int64_t b = 8 * nq * 2 * (int64_t)sizeof(Cand);   // per-split candidates (nsplit <= 8)
   b = align_up(b, 256) + align_up(nt * 4, 256) + align_up(nq * 4, 256);
   b += align_up(((nq + 255) / 256) * 8 + 64, 256);
+  b += align_up(nq * 4, 256) + 256;                  // re-rank list + its counter (L2 / uint8)
   *bytes = b + 1024;
   return SFM_OK;
 }
@@ -369,7 +440,10 @@ extern "C" int sfm_match_knn2(sfm_handle h, int metric, const void* q, int64_t n
   Cand* part = (Cand*)ws;
   int64_t off = align_up(8 * nq * 2 * (int64_t)sizeof(Cand), 256);
   int* tn = (int*)(ws + off); off += align_up(nt * 4, 256);
-  int* qn = (int*)(ws + off);
+  int* qn = (int*)(ws + off); off += align_up(nq * 4, 256);
+  off += align_up(((nq + 255) / 256) * 8 + 64, 256);
+  int* fix_list = (int*)(ws + off); off += align_up(nq * 4, 256);
+  int* fix_cnt = (int*)(ws + off);
   int nsplit = 1;
   if (metric == SFM_METRIC_L2_U8) {
     if (dim != 32 && dim != 64 && dim != 128)
@@ -393,6 +467,13 @@ extern "C" int sfm_match_knn2(sfm_handle h, int metric, const void* q, int64_t n
     else
       hipLaunchKernelGGL((k_knn2_u8<1, QB>), dim3(grid), dim3(256), 0, h->stream, (const uint8_t*)q, nq, (const uint8_t*)t, nt, tn, qn, nsplit, rps, part);
     sfm_prof_end(h, SFM_PROF_KNN);
+    SFM_HIP(h, hipMemsetAsync(fix_cnt, 0, sizeof(int), h->stream));
+    hipLaunchKernelGGL(k_merge_splits_u8, dim3(cdiv(nq, 256)), dim3(256), 0, h->stream, nq, nsplit, part, idx1, idx2, d1, d2,
+                       fix_cnt, fix_list);
+    hipLaunchKernelGGL(k_knn2_u8_rerank, dim3(nq < 2048 ? (unsigned)nq : 2048u), dim3(256), 0, h->stream, (const uint8_t*)q,
+                       (const uint8_t*)t, nt, dim, fix_cnt, fix_list, idx1, idx2, d1, d2);
+    SFM_LAUNCH_CHECK(h, "sfm_match_knn2");
+    return SFM_OK;
   } else if (metric == SFM_METRIC_L2_F32 || metric == SFM_METRIC_HAMMING) {
     nsplit = pick_nsplit(nq, nt, 256);
     const int64_t rps = (nt + nsplit - 1) / nsplit;

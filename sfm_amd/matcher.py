@@ -121,12 +121,18 @@ def ratio_filter(idx1, d1, d2, ratio=0.75, device=0):
 
 
 def match_arrays(desc1, desc2, ratio=0.75, metric="auto", device=0):
-    """(queryIdx, trainIdx, distance) NumPy arrays in query order.  Fewer than two train
-    descriptors make the reference raise at find_matches.py:151; here that yields no matches."""
+    """(queryIdx, trainIdx, distance) NumPy arrays in query order.
+
+    Degenerate inputs follow the reference: with no query or no train descriptors knnMatch hands back
+    an empty list and the ratio loop yields [] (find_matches.py:147-155); with exactly ONE train
+    descriptor every knn row holds a single DMatch and `for m, n in matches` (find_matches.py:151)
+    raises ValueError, which the per-pair try/except at :344-350 turns into a skipped pair."""
     n1 = int(desc1.shape[0]) if desc1 is not None else 0
     n2 = int(desc2.shape[0]) if desc2 is not None else 0
-    if n1 == 0 or n2 < 2:
+    if n1 == 0 or n2 == 0:
         return np.zeros(0, np.int32), np.zeros(0, np.int32), np.zeros(0, np.float32)
+    if n2 == 1:
+        raise ValueError("not enough values to unpack (expected 2, got 1)")
     idx1, _, d1, d2 = knn2(desc1, desc2, metric, device)
     q, t, d = ratio_filter(idx1, d1, d2, ratio, device)
     return q.cpu().numpy(), t.cpu().numpy(), d.cpu().numpy()

@@ -21,6 +21,24 @@ from .rotation import rodrigues, log_so3
 BUNDLE_ADJUST_FREQUENCY = 7      # sfm_reconstruction.py:19 (used by the reference's driver loop)
 
 
+def _flatten_tracks(point_tracks, id_to_idx):
+    """(lens [P], cam_idx [N], uv [N,2]) of the observation dicts, point-major over `track.items()`.
+    The walk over the Python containers runs inside C iterators (itertools / np.fromiter): ~0.3 s per
+    million observations instead of several seconds of per-observation interpreter work."""
+    from itertools import chain
+    lens = np.fromiter(map(len, point_tracks), dtype=np.int64, count=len(point_tracks))
+    n = int(lens.sum())
+    cam_idx = np.fromiter(map(id_to_idx.__getitem__, chain.from_iterable(point_tracks)), dtype=np.int64, count=n)
+    try:
+        uv = np.fromiter(chain.from_iterable(chain.from_iterable(map(dict.values, point_tracks))),
+                         dtype=np.float64, count=2 * n).reshape(n, 2)
+    except (TypeError, ValueError):
+        # pixels stored as something other than flat pairs (e.g. [1,2] arrays): element-wise walk
+        uv = np.asarray([np.asarray(p2, dtype=np.float64).ravel() for tr in point_tracks for p2 in tr.values()],
+                        dtype=np.float64).reshape(-1, 2)
+    return lens, cam_idx, uv
+
+
 def pack_state(poses, points3D, point_tracks, K, cam_dim=10, order="reference"):
     """The packing step of bundle_adjust (sfm_reconstruction.py:409-451), vectorised where the
     reference loops.  Camera index = insertion order of `poses`; observations point-major over
@@ -41,13 +59,15 @@ def pack_state(poses, points3D, point_tracks, K, cam_dim=10, order="reference"):
         cams[i, 3:6] = np.asarray(t, dtype=np.float64).reshape(3)
         if cam_dim == 10:
             cams[i, 6:] = (K[0, 0], K[1, 1], K[0, 2], K[1, 2])
-    pts = np.asarray([np.asarray(p, dtype=np.float64).ravel() for p in points3D], dtype=np.float64).reshape(-1, 3)
-    lens = np.fromiter((len(tr) for tr in point_tracks), dtype=np.int64, count=len(point_tracks))
+    try:
+        pts = np.asarray(points3D, dtype=np.float64)
+        if pts.size != 3 * len(points3D):
+            raise ValueError
+        pts = pts.reshape(-1, 3)
+    except (TypeError, ValueError):
+        pts = np.asarray([np.asarray(p, dtype=np.float64).ravel() for p in points3D], dtype=np.float64).reshape(-1, 3)
+    lens, cam_idx, uv = _flatten_tracks(point_tracks, id_to_idx)
     pt_idx = np.repeat(np.arange(len(point_tracks), dtype=np.int64), lens)
-    cam_idx = np.fromiter((id_to_idx[k] for tr in point_tracks for k in tr.keys()), dtype=np.int64,
-                          count=int(lens.sum()))
-    uv = np.asarray([np.asarray(p2, dtype=np.float64).ravel() for tr in point_tracks for p2 in tr.values()],
-                    dtype=np.float64).reshape(-1, 2)
     if order == "reference":
         perm = np.argsort(cam_idx, kind="stable")
         eff = np.empty_like(uv)
@@ -64,14 +84,24 @@ class BundleAdjustMixin:
     ba_order = "reference"     # bug-compatible residual pairing by default; "aligned" opts out
     ba_cam_dim = 10            # 10 = per-camera intrinsics + regulariser (reference); 6 = fixed K
     ba_device = 0
+    ba_precision = "fp64"      # "mixed": float32 storage of the Jacobian rows / W L^-T, float64 sums and solve
     ba_options = dict(ftol=1e-4, xtol=1e-4, max_nfev=100)     # sfm_reconstruction.py:509-513
     last_ba_result = None
+    last_ba_timing = None      # seconds per phase of the last successful bundle_adjust() call
 
     def bundle_adjust(self):
         """Perform bundle adjustment optimization (sfm_reconstruction.py:401).
-        Returns None on success and False on failure, leaving the state untouched on failure."""
+        Returns None on success and False on failure, leaving the state untouched on failure.
+
+        The reference's call site (:689-690, unguarded) never sees an exception from a solver failure:
+        SciPy reports it through `res.success` (:517-519).  A damped system that is not positive definite,
+        a stalled solve or a non-finite step (SfmNumericError) is therefore logged and returned as False.
+        What SciPy itself raises is raised here too (non-finite residuals at the start point: ValueError);
+        a missing GPU / library still fails loudly (SfmError)."""
+        import time
+        from ._lib import SfmNumericError
         from .ba import GpuBA
-        from .trf import trf
+        t_start = time.perf_counter()
         logging.info("Starting bundle adjustment...")
         if len(self.poses) < 2:
             logging.warning("Not enough cameras for bundle adjustment")
@@ -86,11 +116,20 @@ class BundleAdjustMixin:
             logging.error(f"Error preparing bundle adjustment data: {e}")
             return False
         K0 = (self.K[0, 0], self.K[1, 1], self.K[0, 2], self.K[1, 2])
+        t_packed = time.perf_counter()
         be = GpuBA(cams, pts, cam_idx, pt_idx, uv, K0, float(self.image_width), float(self.image_height),
-                   device=self.ba_device)
+                   device=self.ba_device, precision=self.ba_precision)
         x0 = be.x.clone()
-        res = trf(be, **self.ba_options)
+        t_built = time.perf_counter()
+        try:
+            res = be.run_trf(**self.ba_options)      # the loop of sfm_ba_run_trf (library side)
+        except SfmNumericError as e:
+            if "residuals are not finite" in str(e):
+                raise ValueError("Residuals are not finite in the initial point.") from e    # scipy least_squares.py
+            logging.warning(f"Bundle adjustment failed to converge: {e}")
+            return False
         self.last_ba_result = res
+        t_solved = time.perf_counter()
         if not res.success:
             logging.warning("Bundle adjustment failed to converge: "
                             "The maximum number of function evaluations is exceeded.")
@@ -101,10 +140,12 @@ class BundleAdjustMixin:
         logging.info(f"Bundle adjustment: cost reduced from {cost_initial:.2f} to {cost_final:.2f}")
         cams_new, pts_new = be.params()
         if self.ba_cam_dim == 10:
-            self.K = np.mean([np.array([[c[6], 0, c[8]], [0, c[7], c[9]], [0, 0, 1]]) for c in cams_new], axis=0)
+            self.K = np.mean([np.array([[c[6], 0, c[8]], [0, c[7], c[9]], [0, 0, 1]]) for c in cams_new], axis=0)   # :532-538
         for idx, img_id in enumerate(ids):
             self.poses[img_id] = (rodrigues(cams_new[idx, :3]), cams_new[idx, 3:6].copy())
         self.points3D = pts_new.tolist()
+        self.last_ba_timing = {"pack_state": t_packed - t_start, "create_problem_and_upload": t_built - t_packed,
+                               "solve": t_solved - t_built, "log_norms_and_write_back": time.perf_counter() - t_solved}
         logging.info("Bundle adjustment completed")
 
     def _residual_norm(self, be, x):
@@ -112,26 +153,25 @@ class BundleAdjustMixin:
         err2 = float((be.reproj_errors(x, shared_k=False) ** 2).sum().item())
         if self.ba_cam_dim == 10:
             cams = x[:be.n].reshape(be.C, 10).cpu().numpy()
-            p = be.prob
+            p = be.desc
             reg = np.stack([(cams[:, 6] - p.fx0) / p.fx0, (cams[:, 7] - cams[:, 6]) / cams[:, 6],
                             (cams[:, 8] - p.cx0) / p.width, (cams[:, 9] - p.cy0) / p.height]) * p.reg_weight
             err2 += float((reg ** 2).sum())
         return float(np.sqrt(err2))
 
     def compute_reconstruction_stats(self):
-        """Reprojection / track statistics (sfm_reconstruction.py:582-631) with one shared K."""
-        from .ba import GpuBA
+        """Reprojection / track statistics (sfm_reconstruction.py:582-631) with one shared K.  Needs nothing but
+        the packed arrays: no Schur structure, no workspace (sfm_reproj_errors)."""
+        from .ba import reproj_errors
         n_pts, n_cams = len(self.points3D), len(self.poses)
-        lens = [len(t) for t in self.point_tracks]
-        if n_pts == 0 or sum(lens) == 0:
+        lens = np.fromiter(map(len, self.point_tracks), dtype=np.int64, count=len(self.point_tracks))
+        if n_pts == 0 or lens.sum() == 0:
             return {'mean_reproj_error': 0, 'max_reproj_error': 0, 'mean_track_length': 0,
                     'max_track_length': 0, 'num_points': n_pts, 'num_cameras': n_cams}
         cams, pts, cam_idx, pt_idx, uv, _ = pack_state(self.poses, self.points3D, self.point_tracks,
                                                        self.K, 6, "aligned")
         K0 = (self.K[0, 0], self.K[1, 1], self.K[0, 2], self.K[1, 2])
-        be = GpuBA(cams, pts, cam_idx, pt_idx, uv, K0, float(self.image_width), float(self.image_height),
-                   device=self.ba_device)
-        err = be.reproj_errors()
+        err = reproj_errors(cams, pts, cam_idx, pt_idx, uv, K0, shared_k=True, device=self.ba_device)
         return {'mean_reproj_error': float(err.mean().item()), 'max_reproj_error': float(err.max().item()),
                 'mean_track_length': float(np.mean(lens)), 'max_track_length': float(np.max(lens)),
                 'num_points': n_pts, 'num_cameras': n_cams}
@@ -142,7 +182,7 @@ class StructureFromMotion(BundleAdjustMixin, DriverMixin, ReconstructionIOMixin)
     users who only need the hot path and the driver steps either side of it (sfm_amd.driver); the
     incremental driver loop itself stays the reference's."""
 
-    def __init__(self, data_dir=None, order="reference", cam_dim=10, device=0):
+    def __init__(self, data_dir=None, order="reference", cam_dim=10, device=0, precision="fp64"):
         self.data_dir = Path(data_dir) if data_dir is not None else None
         if self.data_dir is not None:                       # sfm_reconstruction.py:52-54
             self.matches_dir = self.data_dir / 'matches'
@@ -158,6 +198,7 @@ class StructureFromMotion(BundleAdjustMixin, DriverMixin, ReconstructionIOMixin)
         self.ba_order = order
         self.ba_cam_dim = cam_dim
         self.ba_device = device
+        self.ba_precision = precision
 
     def find_image_pairs(self, image_id):
         """Pairs of `image_id` whose other image is already reconstructed (sfm_reconstruction.py:551-580):

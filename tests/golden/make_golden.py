@@ -50,6 +50,9 @@ def load_reference():
     return importlib.import_module("utils.sfm_reconstruction")
 
 
+MAX_NFEV_OVERRIDE = None      # --max-nfev N: the same reference run cut short (parity after a fixed iteration count)
+
+
 def run_reference(m, scene, aligned):
     poses, pts, tracks, K = scene.state()
     s = object.__new__(m.StructureFromMotion)
@@ -65,6 +68,8 @@ def run_reference(m, scene, aligned):
             p2d = cells["points2D"].cell_contents
             perm = np.argsort(cam_idxs, kind="stable")
             p2d[:] = p2d[perm].copy()
+        if MAX_NFEV_OVERRIDE is not None:
+            kw = dict(kw, max_nfev=MAX_NFEV_OVERRIDE)
         res = real(fun, x0, **kw)
         rec.update(x0=np.array(x0), x=res.x.copy(), nfev=res.nfev, njev=res.njev,
                    status=res.status, cost=res.cost, f0_norm=np.linalg.norm(fun(x0)),
@@ -94,12 +99,27 @@ CASES = [
     ("c6p40_cam",   6,  40, None, 0.3, 0.01, 0.005, 16),
     ("c15p200_L6",  15, 200, 6,   0.5, 0.02, 0.005, 17),
     ("c20p300_L5",  20, 300, 5,   0.7, 0.015, 0.008, 18),
+    # BASELINE.json configs[0] at its stated size (10 cameras / 1,000 points / 10,000 observations, n = 3,100,
+    # m = 20,040): ~25 s (literal) + ~55 s (aligned) of the reference's own CPU path on 8 cores
+    ("cfg1_c10p1000", 10, 1000, None, 0.5, 0.02, 0.0, 1001),
 ]
 
 
 def main():
+    global MAX_NFEV_OVERRIDE
+    argv = sys.argv[1:]
+    suffix = ""
+    variants = (False, True)
+    if "--max-nfev" in argv:
+        i = argv.index("--max-nfev")
+        MAX_NFEV_OVERRIDE = int(argv[i + 1])
+        suffix = f"_nfev{MAX_NFEV_OVERRIDE}"
+        del argv[i:i + 2]
+    if "--literal-only" in argv:
+        argv.remove("--literal-only")
+        variants = (False,)
     m = load_reference()
-    only = set(sys.argv[1:])
+    only = set(argv)
     for name, C, P, L, noise, ps, cs, seed in CASES:
         if only and name not in only:
             continue
@@ -108,10 +128,10 @@ def main():
         poses, pts, tracks, K = scene.state()
         R0 = np.stack([poses[k][0] for k in poses])
         t0 = np.stack([np.asarray(poses[k][1]).reshape(3) for k in poses])
-        for aligned in (False, True):
+        for aligned in variants:
             rec = run_reference(m, scene, aligned)
             tag = "aligned" if aligned else "reference"
-            out = os.path.join(HERE, f"ba_{name}_{tag}.npz")
+            out = os.path.join(HERE, f"ba_{name}_{tag}{suffix}.npz")
             np.savez_compressed(
                 out, K=K, R0=R0, t0=t0, pts0=np.asarray(pts), cam_idx=scene.cam_idx,
                 pt_idx=scene.pt_idx, uv=scene.uv, order=tag,

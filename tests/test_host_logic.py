@@ -9,7 +9,7 @@ import sys
 import numpy as np
 import pytest
 
-from conftest import GOLDEN, ROOT, golden_files, load_golden_problem
+from conftest import GOLDEN, ROOT, golden_files, golden_x_tolerance, load_golden_problem
 
 
 # ------------------------------------------------------------------ oracle pinned by the reference's own runs
@@ -169,18 +169,49 @@ def test_library_exports_every_declared_symbol():
     assert b"gfx950" in lib.sfm_version()
 
 
-def test_layout_and_argument_checks_without_gpu():
+def test_argument_checks_without_gpu():
+    """Entry points reject null handles / problems before touching a device (no compute without a GPU)."""
     from sfm_amd import _lib
     lib = _lib.load()
     lay = _lib.BALayout()
-    assert lib.sfm_ba_get_layout(200, 100000, 1000000, 10, 22000, 4000, ctypes.byref(lay)) == 0
-    n = 2000
-    assert lay.reduce_S_count == n * n + n and lay.reduce_q_count == n + 2 and lay.rec_stride == 20 * 8
-    assert lay.reduce_lin_count == 2 * n + 2
-    assert lay.total_bytes < 1 << 30
-    assert lib.sfm_ba_get_layout(200, 100, 1000, 7, 10, 10, ctypes.byref(lay)) != 0       # cam_dim must be 6 or 10
+    assert lib.sfm_ba_get_layout(None, ctypes.byref(lay)) != 0
+    sv = _lib.BAStructureView()
+    assert lib.sfm_ba_get_structure(None, ctypes.byref(sv)) != 0
+    prob = ctypes.c_void_p()
+    desc = _lib.BADesc()
+    assert lib.sfm_ba_create_problem(None, ctypes.byref(desc), ctypes.byref(prob)) != 0 and not prob.value
+    res = _lib.TRFResultC()
+    opt = _lib.TRFOptions()
+    assert lib.sfm_ba_run_trf(None, None, None, ctypes.byref(opt), _lib.REDUCE_FN(), None, ctypes.byref(res)) != 0
+    lib.sfm_ba_destroy_problem(None)                       # no-ops on null
+    lib.sfm_ba_trf_end(None)
     need = ctypes.c_int64()
     assert lib.sfm_match_workspace_bytes(0, 50000, 50000, 128, ctypes.byref(need)) == 0 and need.value > 0
+    # the ctypes mirrors have the sizes the header's structs have on this ABI
+    assert ctypes.sizeof(_lib.BADesc) == 4 * 4 + 8 + 3 * 8 + 7 * 8 + 2 * 4
+    assert ctypes.sizeof(_lib.TRFOptions) == 3 * 8 + 4 * 4 and ctypes.sizeof(_lib.TRFResultC) == 2 * 8 + 6 * 4
+
+
+def test_pack_state_fast_path_equals_plain_walk():
+    """pack_state flattens the track dicts inside C iterators; the result equals a plain per-observation walk,
+    also when pixels are stored as arrays / tuples and camera ids are not strings."""
+    from sfm_amd import synth
+    from sfm_amd.reconstruction import pack_state
+    sc = synth.make_scene(7, 90, obs_per_point=4, seed=3, cam_sigma=0.01)
+    poses, pts, tracks, K = sc.state()
+    tracks[3] = {k: np.asarray(v) for k, v in tracks[3].items()}
+    tracks[4] = {k: tuple(v) for k, v in tracks[4].items()}
+    tracks[5] = {k: np.asarray(v).reshape(1, 2) for k, v in tracks[5].items()}      # forces the fallback walk
+    for order in ("aligned", "reference"):
+        cams, p3, ci, pi, uv, ids = pack_state(poses, pts, tracks, K, 10, order)
+        id_to_idx = {k: i for i, k in enumerate(poses)}
+        ci_ref = np.array([id_to_idx[k] for tr in tracks for k in tr])
+        pi_ref = np.array([j for j, tr in enumerate(tracks) for _ in tr])
+        uv_ref = np.array([np.asarray(v, dtype=np.float64).ravel() for tr in tracks for v in tr.values()])
+        if order == "reference":
+            eff = np.empty_like(uv_ref); eff[np.argsort(ci_ref, kind="stable")] = uv_ref; uv_ref = eff
+        assert np.array_equal(ci, ci_ref) and np.array_equal(pi, pi_ref) and np.array_equal(uv, uv_ref)
+        assert np.array_equal(p3, np.asarray(pts)) and ids == list(poses)
 
 
 def test_product_path_fails_loudly_without_gpu():
@@ -230,9 +261,12 @@ def test_c_oracle_reproduces_reference_run(name):
     from oracle import ba_c
     g, prob, x0 = load_golden_problem(name)
     cb = ba_c.CBA(prob.n_cams, prob.n_pts, 10, prob.cam_idx, prob.pt_idx, prob.uv, prob.K0)
-    x, r = cb.trf(x0)
+    kw = {"max_nfev": int(re.search(r"_nfev(\d+)", name).group(1))} if "_nfev" in name else {}
+    x, r = cb.trf(x0, **kw)
     assert (r["nfev"], r["njev"], r["status"]) == (int(g["nfev"]), int(g["njev"]), int(g["status"]))
-    assert np.max(np.abs(x - g["x"]) / np.maximum(np.abs(g["x"]), 1e-3)) <= 2e-5
+    assert r["cost"] == pytest.approx(float(g["cost"]), rel=1e-6)
+    tol = 2e-5 if golden_x_tolerance(name) == 1e-4 else golden_x_tolerance(name)      # see golden_x_tolerance
+    assert np.max(np.abs(x - g["x"]) / np.maximum(np.abs(g["x"]), 1e-3)) <= tol
 
 
 def test_c_oracle_stages_equal_numpy_oracle():

@@ -89,7 +89,11 @@ def test_match_features_contract(gpu_ready):
     # distances are sqrtf of an integer, like the reference's shipped match files
     d2i = np.rint(d.astype(np.float64) ** 2)
     assert np.array_equal(np.sqrt(d2i.astype(np.float32)), d)
-    assert ImageMatcher().match_features(d1, d2[:1]) == []          # Nt < 2: no matches (documented deviation)
+    # degenerate sizes as the reference: one train row -> ValueError from the unpacking at find_matches.py:151,
+    # no train rows / no query rows -> []
+    with pytest.raises(ValueError, match="not enough values to unpack"):
+        ImageMatcher().match_features(d1, d2[:1])
+    assert ImageMatcher().match_features(d1, d2[:0]) == []
     assert ImageMatcher().match_features(d1[:0], d2) == []
 
 
@@ -105,21 +109,70 @@ def test_ratio_boundary_is_strict(gpu_ready):
     assert (qi.tolist(), ti.tolist(), d.tolist()) == ([0], [0], [2.0])
 
 
-def test_full_size_50k_sampled_parity(gpu_ready):
-    """BASELINE config 2 (50k x 50k x 128): every sampled query row is bit-exact against the oracle,
-    and the match list is query-sorted with in-range indices."""
-    import torch
+def far_apart_sets(nq, nt, dim, seed):
+    """Every pair far apart AND closely spaced: three quarters of the bytes are 0 (query) against 255 (train),
+    the rest differ by 0..2, so all d^2 sit within ~100 of 0.75 * dim * 255^2 (6.2e6 at dim 128, above 2^22),
+    where about one in five neighbouring integers shares its float32 root with the next."""
+    rng = np.random.default_rng(seed)
+    near = dim // 4
+    q = np.zeros((nq, dim), np.uint8)
+    t = np.full((nt, dim), 255, np.uint8)
+    q[:, dim - near:] = 128 + rng.integers(0, 2, size=(nq, near))
+    t[:, dim - near:] = 128 + rng.integers(0, 3, size=(nt, near))
+    return q, t
+
+
+@pytest.mark.parametrize("nq,nt,dim", [(300, 5000, 128), (70, 700, 128), (129, 2100, 64)])
+def test_l2_u8_sqrtf_collisions_follow_the_float_ranking(gpu_ready, nq, nt, dim):
+    """d^2 in [2^22, 8.3e6]: distinct integer d^2 round to the same float32 distance and OpenCV's rule (compare
+    the float32 values, lower train index first) picks a different neighbour than ranking on the integers.  The
+    kernel ranks on integers and re-ranks exactly these queries on the float32 value (k_knn2_u8_rerank); both
+    oracles (NumPy, C) rank on the float32 value.  Train sets span several LDS chunks and splits."""
+    from oracle import matcher_oracle as mo, ba_c
+    q, t = far_apart_sets(nq, nt, dim, seed=nt)
+    ref = mo.knn2(q, t, "l2")
+    assert (ref[2].astype(np.float64) ** 2).min() >= 2 ** 22 or dim < 128     # dim <= 64: d^2 <= 64 * 255^2 < 2^22, no collisions exist
+    got = gpu_knn2(q, t, "l2")
+    assert_knn_equal(got, ref)
+    assert_knn_equal(got, ba_c.knn2_u8(q, t))
+    # the case is adversarial for an integer ranking: it would pick other neighbours for some queries
+    ai, bi = q.astype(np.int64), t.astype(np.int64)
+    d2 = (ai * ai).sum(1)[:, None] + (bi * bi).sum(1)[None, :] - 2 * (ai @ bi.T)
+    int_best = np.argmin(d2, axis=1)
+    if dim == 128:
+        assert np.any(int_best != ref[0]), "no float32 collision decided a neighbour: the case does not test the rule"
+
+
+def test_l2_u8_mixed_near_and_far_rows(gpu_ready):
+    """Ordinary SIFT-like queries and far-apart ones in one call: only the far ones take the re-rank path."""
     from oracle import matcher_oracle as mo
+    from sfm_amd import synth
+    d1, d2 = synth.make_descriptors(400, 3000, seed=77)
+    q = d1.astype(np.uint8); t = d2.astype(np.uint8)
+    q[::8] = 0                                     # all-zero queries: nearest neighbours are ordinary rows (d^2 ~ 2^18)
+    q[5:55] = 255                                  # all-255 queries: every SIFT-like train row is > 2^22 away
+    q[5:55, :8] = np.random.default_rng(9).integers(250, 256, size=(50, 8))
+    assert_knn_equal(gpu_knn2(q, t, "l2"), mo.knn2(q, t, "l2"))
+
+
+def test_full_size_50k_all_rows(gpu_ready):
+    """BASELINE config 2 (50k x 50k x 128): EVERY query row bit-exact against the C oracle (same float32 ranking
+    rule as the NumPy oracle, tests/test_matcher_oracle.py checks the two against each other), and the match
+    list is query-sorted with in-range indices."""
+    import torch
+    from oracle import ba_c, matcher_oracle as mo
     from sfm_amd import synth, matcher
     d1, d2 = synth.make_descriptors(50000, 50000, seed=1002)
     u1, u2 = d1.astype(np.uint8), d2.astype(np.uint8)
     i1, i2, a, b = matcher.knn2(torch.from_numpy(u1).cuda(), torch.from_numpy(u2).cuda(), "l2")
-    rows = np.random.default_rng(0).choice(50000, size=384, replace=False)
-    ref = mo.knn2(u1[rows], u2, "l2")
-    got = (i1.cpu().numpy()[rows], i2.cpu().numpy()[rows], a.cpu().numpy()[rows], b.cpu().numpy()[rows])
-    assert_knn_equal(got, ref)
+    got = (i1.cpu().numpy(), i2.cpu().numpy(), a.cpu().numpy(), b.cpu().numpy())
+    assert_knn_equal(got, ba_c.knn2_u8(u1, u2))
+    rows = np.random.default_rng(0).choice(50000, size=256, replace=False)
+    assert_knn_equal(tuple(g[rows] for g in got), mo.knn2(u1[rows], u2, "l2"))
     q, t, d = matcher.ratio_filter(i1, a, b, 0.75)
     q, t = q.cpu().numpy(), t.cpu().numpy()
     assert np.all(np.diff(q) > 0) and t.min() >= 0 and t.max() < 50000
-    keep = a.cpu().numpy().astype(np.float64) < 0.75 * b.cpu().numpy().astype(np.float64)
+    keep = got[2].astype(np.float64) < 0.75 * got[3].astype(np.float64)
     assert np.array_equal(q, np.nonzero(keep)[0])
+    rq, rt, rd = mo.ratio_filter(got[0], got[2], got[3], 0.75)
+    assert np.array_equal(t, rt) and np.array_equal(d.cpu().numpy(), rd)

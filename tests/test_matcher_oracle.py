@@ -20,7 +20,32 @@ def test_known_answers_ties_and_ratio():
     t[1, 0] = 2
     qi, ti, d = mo.match_features(q, t)
     assert qi.tolist() == [0, 1] and ti.tolist() == [1, 1] and d.tolist() == [2.0, 2.0]
-    assert len(mo.match_features(q, t[:1])[0]) == 0                # Nt < 2
+    # degenerate sizes as the reference: one train row -> the unpacking at find_matches.py:151 raises; none -> []
+    import pytest
+    with pytest.raises(ValueError, match="not enough values to unpack"):
+        mo.match_features(q, t[:1])
+    assert len(mo.match_features(q, t[:0])[0]) == 0 and len(mo.match_features(q[:0], t)[0]) == 0
+
+
+def test_c_and_numpy_oracles_agree_incl_sqrtf_collisions():
+    """The two restatements rank on the float32 distance (lower train index on ties): ordinary SIFT-like sets and
+    far-apart sets (d^2 >= 2^22, where distinct integers share a float32 root and the rule decides neighbours)."""
+    from oracle import matcher_oracle as mo, ba_c
+    from sfm_amd import synth
+    d1, d2 = synth.make_descriptors(300, 900, seed=2)
+    u1, u2 = d1.astype(np.uint8), d2.astype(np.uint8)
+    for a, b in zip(mo.knn2(u1, u2), ba_c.knn2_u8(u1, u2)):
+        assert np.array_equal(a, b)
+    rng = np.random.default_rng(4)
+    q = np.zeros((300, 128), np.uint8); t = np.full((5000, 128), 255, np.uint8)
+    q[:, 96:] = 128 + rng.integers(0, 2, size=(300, 32))          # all d^2 within ~100 of 96 * 255^2 = 6.2e6
+    t[:, 96:] = 128 + rng.integers(0, 3, size=(5000, 32))
+    ref = mo.knn2(q, t)
+    for a, b in zip(ref, ba_c.knn2_u8(q, t)):
+        assert np.array_equal(a, b)
+    ai, bi = q.astype(np.int64), t.astype(np.int64)
+    d2i = (ai * ai).sum(1)[:, None] + (bi * bi).sum(1)[None, :] - 2 * (ai @ bi.T)
+    assert d2i.min() >= 2 ** 22 and np.any(np.argmin(d2i, axis=1) != ref[0])      # the rule is exercised
 
 
 def test_integer_path_equals_float_path():
