@@ -205,8 +205,8 @@ def main():
                       "same scene, camera block [rvec,t] with fixed K (cam_dim 6, n = %d)" % (6 * C))
     if not args.no_mixed:
         rm = fixed_schedule_run(d, "mixed", True)
-        ba_mixed = brief(rm, "same scene and schedule, SFM_BA_MIXED: Jacobian rows and W L^-T stored in float32, "
-                             "all sums / S / solve in float64 (opt-in; the headline stays float64)")
+        ba_mixed = brief(rm, "same scene and schedule, SFM_BA_MIXED: Jacobian rows stored in float32, every sum / W L^-T / S / "
+                             "solve in float64 (opt-in; the headline stays float64)")
         ba_mixed["kernels_us"] = {k: round(v[0] / v[1] * 1e3, 2) for k, v in rm["prof"].items() if v[1] > 0}
 
     # ------------------------------------------------------------------ end-to-end drop-in call (N = 1 only)

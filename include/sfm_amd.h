@@ -99,7 +99,7 @@ int sfm_match_f32_to_u8(sfm_handle h, const float* src, int64_t n_elems, uint8_t
 /* What bundle_adjust packs before it calls SciPy (sfm_reconstruction.py:409-451) - nothing kernel-specific.
  * cam_idx / pt_idx / uv may be host or device pointers; sfm_ba_create_problem copies them. */
 enum { SFM_BA_FP64 = 0,    /* every intermediate in float64 (default; the reference's arithmetic) */
-       SFM_BA_MIXED = 1 }; /* Jacobian rows and W L^-T stored in float32, all sums / S / the solve in float64 */
+       SFM_BA_MIXED = 1 }; /* Jacobian rows (and scaled residuals) stored in float32; every sum, W L^-T, S and the solve in float64 */
 typedef struct {
   int32_t n_cams, n_pts, cam_dim, apply_reg;   /* apply_reg: add the 4 regulariser rows per camera (:489-499); rank 0 only */
   int64_t n_obs;
@@ -167,8 +167,8 @@ enum { SFM_SC_COST = 0, SFM_SC_GNORM2 = 1, SFM_SC_GINF = 2, SFM_SC_PNORM2 = 3, S
        SFM_SC_CHOL_FAIL = 10, SFM_SC_HDIAG = 11 /* max diag(H) */, SFM_SC_COUNT = 16 };
 
 /* Layout of the workspace of a problem.  The workspace (total_bytes, device memory) is the caller's: bind it
- * before the first stage; workspace == NULL makes the library allocate (and own) one.  rec / recB / G hold
- * float32 values when the problem was created with SFM_BA_MIXED (rec_stride etc. are in bytes). */
+ * before the first stage; workspace == NULL makes the library allocate (and own) one.  rec / recB hold
+ * float32 values when the problem was created with SFM_BA_MIXED (rec_stride is in bytes); G is always float64. */
 int sfm_ba_get_layout(sfm_ba_problem p, sfm_ba_layout* out_host);
 int sfm_ba_bind_workspace(sfm_handle h, sfm_ba_problem p, void* workspace, int64_t workspace_bytes);
 

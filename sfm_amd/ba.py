@@ -29,8 +29,8 @@ class GpuBA:
     /root/reference/utils/sfm_reconstruction.py:416-427; d = 6: rvec,t with shared K0),
     pts [P,3], observations point-major as the reference packs them (:430-435).  Only these packed
     arrays go in: the index structure of the Schur complement is built on the device by
-    sfm_ba_create_problem.  precision="mixed" stores the Jacobian rows and W L^-T in float32
-    (all sums, S and the solve stay float64).
+    sfm_ba_create_problem.  precision="mixed" stores the Jacobian rows in float32 (every sum, W L^-T, S and
+    the solve stay float64).
     """
 
     def __init__(self, cams, pts, cam_idx, pt_idx, uv, K0, width=1024.0, height=768.0,

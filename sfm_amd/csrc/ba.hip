@@ -9,9 +9,13 @@
 //   recA   [N][2D]    per observation, point-major: Jc~ rows (2xD)
 //   recB   [N][8]     per observation: Jp~ rows (2x3), f~ (2)
 //   G      [N][GS]    per observation, per alpha: W_k L_j^-T as [3][D]  (L_j L_j^T = C_j + alpha I)
-// These three are the bulk of the traffic.  Their storage type T is double, or float in SFM_BA_MIXED (then a G
-// block is padded to GS = 32 / 20 floats so that it is a whole number of 16-byte chunks; D = 10: one 128-byte
-// line).  Every sum over them (B, C, g, S, the step) is accumulated in float64 in both modes.
+// These three are the bulk of the traffic.  SFM_BA_MIXED stores the Jacobian records recA / recB in float32 (the
+// "mixed-precision Jacobian" of BASELINE.json config 5); everything derived from them - B, C, g, G, S, the step - is
+// computed and kept in float64 FROM THE ROUNDED ROWS, so S stays the exact Schur complement of a (slightly
+// perturbed) Jacobian and therefore positive definite for every alpha > 0.  G itself must not be rounded: with G in
+// float32 S = B - sum G G^T loses definiteness in the 7 gauge directions (eigenvalue alpha) as soon as
+// alpha < ~1e-7 max diag(H) - measured: the zero-noise goldens then fail in the factorisation (the kernels keep the
+// storage type of G as a template parameter; only double is instantiated).
 //   S | r  [(n+1)][n] reduced camera system with its right-hand side as a bordered row
 // Observations of one point (a track) are contiguous; cameras are reached through cam_obs.
 #include "ba_internal.h"
@@ -44,7 +48,7 @@ Lay ba_layout(int64_t C, int64_t P, int64_t N, int64_t D, int64_t n_items, int64
   L.e = take(P * 3);
   L.v = take(P * 3);
   L.tmp3 = take(N * 3);
-  L.G = take_rec(N * ba_g_stride((int)D, precision));
+  L.G = take(N * 3 * D);                           // always float64 (see the header of this file)
   L.red_lin = take(2 * n + 2);
   L.gmax = take(2);
   L.red_S = take(n * n + n);
@@ -499,10 +503,10 @@ __global__ void k_point_factor(int P, double alpha, const double* __restrict__ C
 // G_k[m][a] = sum_r Jc~[r][a] * V[r][m],  V = Jp~ M^T (2x3).  16 lanes per observation (a = lane & 15 < D),
 // each lane produces the three m entries of its column: Jc~ reads and G writes are contiguous over a, the
 // 12 doubles of Jp~ and M are the same address for the whole group (one request per group).
-template <int D, typename T, int GS>
+template <int D, typename T, typename TG, int GS>
 __global__ __launch_bounds__(256) void k_build_G(int64_t N, const int* __restrict__ pt_idx,
                                                  const T* __restrict__ recA, const T* __restrict__ recB,
-                                                 const double* __restrict__ Linv, T* __restrict__ G) {
+                                                 const double* __restrict__ Linv, TG* __restrict__ G) {
   const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
   const int64_t k = t >> 4;
   const int a = (int)(t & 15);
@@ -513,11 +517,11 @@ __global__ __launch_bounds__(256) void k_build_G(int64_t N, const int* __restric
   const double j0 = jp[0], j1 = jp[1], j2 = jp[2], j3 = jp[3], j4 = jp[4], j5 = jp[5];
   const double m00 = M[0], m10 = M[1], m11 = M[2], m20 = M[3], m21 = M[4], m22 = M[5];
   const double c0 = r[a], c1 = r[D + a];
-  T* g = G + (size_t)k * GS + a;
-  g[0] = (T)(c0 * (j0 * m00) + c1 * (j3 * m00));
-  g[D] = (T)(c0 * (j0 * m10 + j1 * m11) + c1 * (j3 * m10 + j4 * m11));
-  g[2 * D] = (T)(c0 * (j0 * m20 + j1 * m21 + j2 * m22) + c1 * (j3 * m20 + j4 * m21 + j5 * m22));
-  if (GS > 3 * D && a < GS - 3 * D) g[3 * D] = (T)0;     // padding of the block (read as part of a 16-byte chunk, never used)
+  TG* g = G + (size_t)k * GS + a;
+  g[0] = (TG)(c0 * (j0 * m00) + c1 * (j3 * m00));
+  g[D] = (TG)(c0 * (j0 * m10 + j1 * m11) + c1 * (j3 * m10 + j4 * m11));
+  g[2 * D] = (TG)(c0 * (j0 * m20 + j1 * m21 + j2 * m22) + c1 * (j3 * m20 + j4 * m21 + j5 * m22));
+  if (GS > 3 * D && a < GS - 3 * D) g[3 * D] = (TG)0;     // padding of the block (read as part of a 16-byte chunk, never used)
 }
 
 // Reduced camera system  S[c][c2] = [c == c2] B_c - sum_{(k,k2) on a shared track} G_k G_k2^T  (c <= c2, mirrored).
@@ -926,12 +930,12 @@ static int check_problem(sfm_ctx* h, sfm_ba_problem p, Lay* L) {
     if ((D) == 10) { constexpr int DD = 10; __VA_ARGS__; } \
     else { constexpr int DD = 6; __VA_ARGS__; }            \
   } while (0)
-// camera block width DD, storage type TT of the record arrays, G block stride GG (elements)
+// camera block width DD, storage type TT of the Jacobian records, G block stride GG (doubles; G is always float64)
 #define DISPATCH_DT(D, PREC, ...)                                                                     \
   do {                                                                                                \
     if ((PREC) == SFM_BA_MIXED) {                                                                     \
-      if ((D) == 10) { constexpr int DD = 10; constexpr int GG = 32; typedef float TT; __VA_ARGS__; } \
-      else { constexpr int DD = 6; constexpr int GG = 20; typedef float TT; __VA_ARGS__; }            \
+      if ((D) == 10) { constexpr int DD = 10; constexpr int GG = 30; typedef float TT; __VA_ARGS__; } \
+      else { constexpr int DD = 6; constexpr int GG = 18; typedef float TT; __VA_ARGS__; }            \
     } else {                                                                                          \
       if ((D) == 10) { constexpr int DD = 10; constexpr int GG = 30; typedef double TT; __VA_ARGS__; } \
       else { constexpr int DD = 6; constexpr int GG = 18; typedef double TT; __VA_ARGS__; }           \
@@ -1067,18 +1071,18 @@ extern "C" int sfm_ba_schur_build(sfm_handle h, sfm_ba_problem p, double alpha) 
   hipLaunchKernelGGL(k_point_factor, dim3(cdiv(P, 256)), dim3(256), 0, h->stream, P, alpha, WS(L, Cp), WS(L, gp),
                      WS(L, Linv), WS(L, e));
   DISPATCH_DT(D, p->precision, {
-    hipLaunchKernelGGL((k_build_G<DD, TT, GG>), dim3(cdiv(N * 16, 256)), dim3(256), 0, h->stream, N, p->pt_idx, WST(L, recA),
-                       WST(L, recB), WS(L, Linv), WST(L, G));
+    hipLaunchKernelGGL((k_build_G<DD, TT, double, GG>), dim3(cdiv(N * 16, 256)), dim3(256), 0, h->stream, N, p->pt_idx, WST(L, recA),
+                       WST(L, recB), WS(L, Linv), WS(L, G));
     sfm_prof_end(h, SFM_PROF_BUILD_G);
     sfm_prof_begin(h, SFM_PROF_SCHUR);
     if (p->n_items > 0)   // 8 groups x ceil(largest group / 4) workgroups
-      hipLaunchKernelGGL((k_schur_items<DD, TT, GG>), dim3(8 * cdiv(p->xcd_max_items, 4)), dim3(256), 0, h->stream,
-                         p->xcd_ptr, p->xcd_items, p->item_beg, p->item_end, p->pair_k, p->pair_k2, WST(L, G), WS(L, sch_part));
+      hipLaunchKernelGGL((k_schur_items<DD, double, GG>), dim3(8 * cdiv(p->xcd_max_items, 4)), dim3(256), 0, h->stream,
+                         p->xcd_ptr, p->xcd_items, p->item_beg, p->item_end, p->pair_k, p->pair_k2, WS(L, G), WS(L, sch_part));
     hipLaunchKernelGGL(k_schur_assemble<DD>, dim3(C, cdiv(C, 2)), dim3(256), 0, h->stream, C, p->item_ptr,
                        WS(L, sch_part), WS(L, B), WS(L, red_S));
     if (p->n_cchunks > 0)
-      hipLaunchKernelGGL((k_cam_reduce_chunks<DD, TT, GG>), dim3((unsigned)p->n_cchunks), dim3(256), 0, h->stream, p->cch_beg,
-                         p->cch_end, p->cam_obs, p->pt_idx, WST(L, G), WS(L, e), WS(L, cch_part));
+      hipLaunchKernelGGL((k_cam_reduce_chunks<DD, double, GG>), dim3((unsigned)p->n_cchunks), dim3(256), 0, h->stream, p->cch_beg,
+                         p->cch_end, p->cam_obs, p->pt_idx, WS(L, G), WS(L, e), WS(L, cch_part));
     hipLaunchKernelGGL(k_cam_reduce_final<DD>, dim3(cdiv(n, 256)), dim3(256), 0, h->stream, C, p->cch_ptr,
                        WS(L, cch_part), WS(L, gc), WS(L, red_S) + (size_t)n * n);
     sfm_prof_end(h, SFM_PROF_SCHUR);
@@ -1129,8 +1133,8 @@ extern "C" int sfm_ba_schur_solve(sfm_handle h, sfm_ba_problem p, double alpha, 
   rc = dense_trsv(h, n, dw, WS(L, tvec), WS(L, pc), 1); if (rc) return rc;
   sfm_prof_end(h, SFM_PROF_TRSV);
   sfm_prof_begin(h, SFM_PROF_BACKSUB);
-  DISPATCH_DT(D, p->precision, hipLaunchKernelGGL((k_obs_Gtp<DD, TT, GG>), dim3(cdiv(N * 3, 256)), dim3(256), 0, h->stream, N * 3,
-                                                  p->cam_idx, WST(L, G), WS(L, pc), WS(L, tmp3)));
+  DISPATCH_DT(D, p->precision, hipLaunchKernelGGL((k_obs_Gtp<DD, double, GG>), dim3(cdiv(N * 3, 256)), dim3(256), 0, h->stream, N * 3,
+                                                  p->cam_idx, WS(L, G), WS(L, pc), WS(L, tmp3)));
   hipLaunchKernelGGL(k_backsub, dim3((unsigned)L.nblk_pt), dim3(256), 0, h->stream, P, p->pt_ptr, WS(L, tmp3),
                      WS(L, Linv), WS(L, e), WS(L, pp), WS(L, v), WS(L, part_pt));
   hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(256), 0, h->stream, WS(L, part_pt), (int)L.nblk_pt, 2,
@@ -1138,8 +1142,8 @@ extern "C" int sfm_ba_schur_solve(sfm_handle h, sfm_ba_problem p, double alpha, 
   if (want_q) {
     DISPATCH_DT(D, p->precision, {
       if (p->n_cchunks > 0)
-        hipLaunchKernelGGL((k_cam_reduce_chunks<DD, TT, GG>), dim3((unsigned)p->n_cchunks), dim3(256), 0, h->stream, p->cch_beg,
-                           p->cch_end, p->cam_obs, p->pt_idx, WST(L, G), WS(L, v), WS(L, cch_part));
+        hipLaunchKernelGGL((k_cam_reduce_chunks<DD, double, GG>), dim3((unsigned)p->n_cchunks), dim3(256), 0, h->stream, p->cch_beg,
+                           p->cch_end, p->cam_obs, p->pt_idx, WS(L, G), WS(L, v), WS(L, cch_part));
       hipLaunchKernelGGL(k_cam_reduce_final<DD>, dim3(cdiv(n, 256)), dim3(256), 0, h->stream, C, p->cch_ptr,
                          WS(L, cch_part), (const double*)nullptr, WS(L, red_q));
     });

@@ -32,8 +32,6 @@ struct sfm_ba_prob {
 };
 
 Lay ba_layout(int64_t C, int64_t P, int64_t N, int64_t D, int64_t n_items, int64_t n_cchunks, int precision);
-// width of the per-observation records in storage elements (double, or float in mixed precision)
-static inline int ba_g_stride(int D, int precision) { return precision == SFM_BA_MIXED ? (D == 10 ? 32 : 20) : 3 * D; }
 
 // growable per-handle device scratch (stream-ordered use only)
 void* sfm_scratch(sfm_ctx* h, size_t bytes);

