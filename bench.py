@@ -279,6 +279,35 @@ def main():
                    "ms_per_pair_of_images": tm / args.match_reps * 1e3, "n_matches": int(mq.shape[0]),
                    "dtype": "u8/i32", "roofline": mroof}
 
+    # ---- the reference's real call pattern: one match_features per image pair of a preprocessing step
+    # (find_matches.py:329-350), a few hundred to a few thousand descriptors per image: all pairs in ONE launch
+    # (match_pairs) beside the per-pair loop, host arrays in, match arrays out (uploads included on both sides)
+    if matcher is not None and rank == 0 and world == 1:
+        try:
+            rows = []
+            rng = np.random.default_rng(7)
+            for per_image in (500, 2000):
+                n_img = 18
+                base, _ = synth.make_descriptors(per_image + 200, 2, seed=77)
+                imgs = [np.clip(base[rng.permutation(base.shape[0])[:per_image]] +
+                                np.rint(rng.normal(0, 5.0, size=(per_image, 128))), 0, 255).astype(np.uint8) for _ in range(n_img)]
+                pairs = [(i, j) for i in range(n_img) for j in range(i + 1, n_img)][:148]      # the bunny set verified 148 pairs
+                mt.match_pairs(imgs, pairs); [mt.match_arrays(imgs[i], imgs[j]) for i, j in pairs[:4]]
+                torch.cuda.synchronize(); t0 = time.perf_counter()
+                got = mt.match_pairs(imgs, pairs)
+                torch.cuda.synchronize(); tb = time.perf_counter() - t0
+                t0 = time.perf_counter()
+                loop = [mt.match_arrays(imgs[i], imgs[j]) for i, j in pairs]
+                torch.cuda.synchronize(); tl = time.perf_counter() - t0
+                same = all(np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2])
+                           for a, b in zip(got, loop))
+                rows.append({"pairs": len(pairs), "descriptors_per_image": per_image, "batched_ms": tb * 1e3,
+                             "per_pair_loop_ms": tl * 1e3, "speedup": tl / tb, "identical_results": bool(same),
+                             "pairs_per_s_batched": len(pairs) * per_image * per_image / tb})
+            matcher["batched_image_pairs"] = rows
+        except Exception as e:
+            matcher["batched_image_pairs"] = {"error": repr(e)}
+
     # ------------------------------------------------------------------ driver-row kernels, N = 1 only
     driver_rows = None
     if rank == 0 and world == 1 and not args.no_driver_rows:

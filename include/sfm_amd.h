@@ -76,6 +76,29 @@ int sfm_match_ratio(sfm_handle h, int64_t nq, const int32_t* idx1, const float* 
                     double ratio, int32_t* query_idx, int32_t* train_idx, float* dist,
                     int64_t* n_matches, void* workspace, int64_t workspace_bytes);
 
+/* Batched form: every image pair of a preprocessing step in ONE call.  The reference calls match_features once per
+ * pair in a serial loop (find_matches.py:329-350, call at :272) on sets of a few hundred to a few thousand
+ * descriptors, where a launch per pair is all overhead.  Segment s (= one pair) matches the query rows
+ * [q_beg[s], q_end[s]) of q against the train rows [t_beg[s], t_end[s]) of t (q and t may be the same array holding
+ * the descriptors of all images back to back).  Output row out_ptr[s] + i belongs to query row q_beg[s] + i;
+ * out_ptr = exclusive prefix sum of the query counts, n_out = out_ptr[n_seg].  idx1 / idx2 are train indices
+ * RELATIVE to t_beg[s] (what DMatch.trainIdx is for that pair).  Results per segment are bit-identical to a
+ * sfm_match_knn2 call on that pair.  The four segment arrays are HOST pointers (the caller knows its image sizes);
+ * out_ptr_device (optional, [n_seg+1] device int64) receives out_ptr for sfm_match_ratio_batched. */
+int sfm_match_batched_workspace_bytes(int metric, int32_t n_seg, const int64_t* q_beg_host, const int64_t* q_end_host,
+                                      const int64_t* t_beg_host, const int64_t* t_end_host, int64_t nq_rows,
+                                      int64_t nt_rows, int64_t* n_out_host, int64_t* bytes_host);
+int sfm_match_knn2_batched(sfm_handle h, int metric, const void* q, int64_t nq_rows, const void* t, int64_t nt_rows,
+                           int dim, int32_t n_seg, const int64_t* q_beg_host, const int64_t* q_end_host,
+                           const int64_t* t_beg_host, const int64_t* t_end_host, int32_t* idx1, int32_t* idx2,
+                           float* d1, float* d2, int64_t* out_ptr_device, void* workspace, int64_t workspace_bytes);
+/* Ratio test + compaction over all n_out rows of a batch: the matches of segment s are entries
+ * [seg_match_ptr[s], seg_match_ptr[s+1]) (device int64 [n_seg+1]) of query_idx / train_idx / dist, query indices
+ * relative to the segment (DMatch.queryIdx), in query order.  workspace: ceil(n_out / 256) * 8 + 64 bytes. */
+int sfm_match_ratio_batched(sfm_handle h, int64_t n_out, int32_t n_seg, const int64_t* out_ptr_device, const int32_t* idx1,
+                            const float* d1, const float* d2, double ratio, int32_t* query_idx, int32_t* train_idx,
+                            float* dist, int64_t* seg_match_ptr_device, void* workspace, int64_t workspace_bytes);
+
 /* float32 descriptors whose every value is an integer in [0,255] (what SIFT emits) -> uint8 copy;
  * *all_integral (device int32) is 0 if any value is not such an integer. */
 int sfm_match_f32_to_u8(sfm_handle h, const float* src, int64_t n_elems, uint8_t* dst, int32_t* all_integral);

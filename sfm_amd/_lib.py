@@ -72,6 +72,9 @@ SIGNATURES = {
     "sfm_match_knn2": (C.c_int, [vp, C.c_int, vp, i64, vp, i64, C.c_int, vp, vp, vp, vp, vp, i64]),
     "sfm_match_ratio": (C.c_int, [vp, i64, vp, vp, vp, f64, vp, vp, vp, vp, vp, i64]),
     "sfm_match_f32_to_u8": (C.c_int, [vp, vp, i64, vp, vp]),
+    "sfm_match_batched_workspace_bytes": (C.c_int, [C.c_int, i32, vp, vp, vp, vp, i64, i64, C.POINTER(i64), C.POINTER(i64)]),
+    "sfm_match_knn2_batched": (C.c_int, [vp, C.c_int, vp, i64, vp, i64, C.c_int, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i64]),
+    "sfm_match_ratio_batched": (C.c_int, [vp, i64, i32, vp, vp, vp, vp, f64, vp, vp, vp, vp, vp, i64]),
     "sfm_copy_to_host": (C.c_int, [vp, vp, vp, i64]),
     "sfm_ba_create_problem": (C.c_int, [vp, C.POINTER(BADesc), C.POINTER(vp)]),
     "sfm_ba_destroy_problem": (None, [vp]),

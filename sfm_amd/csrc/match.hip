@@ -19,6 +19,7 @@
 // float32 value over the whole train set by k_knn2_u8_rerank (k_merge_splits_u8 lists them).
 #include "common.h"
 #include <cstdlib>
+#include <vector>
 
 typedef int v4i __attribute__((ext_vector_type(4)));
 typedef int v16i __attribute__((ext_vector_type(16)));
@@ -31,6 +32,23 @@ typedef int v16i __attribute__((ext_vector_type(16)));
 __device__ __forceinline__ float sqrt_rn_f32(float x) { return (float)sqrt((double)x); }
 
 struct Cand { float d; int i; };   // distance (already sqrtf'ed / popcount), train index; i < 0 = empty
+
+// Batched (segmented) matching: one launch covers every image pair of a preprocessing step
+// (find_matches.py:329-350 calls match_features once per pair, serially).  A segment = one pair = a range of query
+// rows against a range of train rows; the host cuts the segments into workgroup-sized pieces (plan_segments) and
+// every workgroup of the distance kernels reads its piece from this record.  wg == nullptr = one segment covering
+// the whole arrays, pieces computed from blockIdx as before.
+struct MatchWG {
+  int64_t q_first, q_end;     // query rows of this workgroup: [q_first, min(q_first + rows per workgroup, q_end))
+  int64_t t_first, t_end;     // train rows of this workgroup's split
+  int64_t t_seg;              // first train row of the segment: train indices are reported relative to it
+  int64_t out_first;          // output row of q_first
+  int32_t split, pad;
+};
+struct MatchSegs {            // device copies of the segment table, for the kernels that work per output row
+  const int64_t *q_beg, *t_beg, *t_end, *out_ptr;
+  int32_t n_seg;
+};
 
 __device__ __forceinline__ bool cand_less(float d, int i, float d2, int i2) {
   return (d < d2) || (d == d2 && (unsigned)i < (unsigned)i2);   // i = -1 (empty) sorts last
@@ -66,7 +84,8 @@ template <int KS, int QB>   // KS = dim / 32
 __global__ __launch_bounds__(256) void k_knn2_u8(const uint8_t* __restrict__ q, int64_t nq,
                                                  const uint8_t* __restrict__ t, int64_t nt,
                                                  const int* __restrict__ tn, const int* __restrict__ qn,
-                                                 int nsplit, int64_t rows_per_split, Cand* __restrict__ part) {
+                                                 int nsplit, int64_t rows_per_split, const MatchWG* __restrict__ wg,
+                                                 int64_t total_out, Cand* __restrict__ part) {
   constexpr int DIM = KS * 32;
   constexpr int GPR = DIM / 16;                 // 16-byte granules per row
   constexpr int CHUNK = 128;                   // rows per LDS chunk (2 x 16 KiB at dim 128)
@@ -74,11 +93,22 @@ __global__ __launch_bounds__(256) void k_knn2_u8(const uint8_t* __restrict__ q, 
   __shared__ uint4 s_t[2][CHUNK * GPR];
   __shared__ int s_k0[2][CHUNK];
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, half = lane >> 5, l31 = lane & 31;
-  const int split = blockIdx.x % nsplit;
-  const int64_t qblock = blockIdx.x / nsplit;
-  const int64_t t_beg = (int64_t)split * rows_per_split;
-  const int64_t t_end = (t_beg + rows_per_split) < nt ? (t_beg + rows_per_split) : nt;
-  const int64_t q0 = qblock * (4 * QB * 32) + (int64_t)w * (QB * 32);
+  int split;
+  int64_t t_beg, t_end, q0, t_seg = 0, out_shift = 0;     // out_shift: output row = query row + out_shift
+  if (wg) {
+    const MatchWG r = wg[blockIdx.x];
+    split = r.split; t_beg = r.t_first; t_end = r.t_end; t_seg = r.t_seg;
+    q0 = r.q_first + (int64_t)w * (QB * 32);
+    nq = r.q_end;
+    out_shift = r.out_first - r.q_first;
+  } else {
+    split = blockIdx.x % nsplit;
+    const int64_t qblock = blockIdx.x / nsplit;
+    t_beg = (int64_t)split * rows_per_split;
+    t_end = (t_beg + rows_per_split) < nt ? (t_beg + rows_per_split) : nt;
+    q0 = qblock * (4 * QB * 32) + (int64_t)w * (QB * 32);
+    total_out = nq;
+  }
 
   // query fragments: lane holds bytes [32 ks + 16 half, +16) of query q0 + 32 qb + l31
   v4i bq[QB][KS];
@@ -184,7 +214,7 @@ __global__ __launch_bounds__(256) void k_knn2_u8(const uint8_t* __restrict__ q, 
     }
     // every second chunk (and at the end): unpack the window's best two and merge into the running pair
     // (later windows = higher indices, so strict '<' keeps the lower index on equal d^2)
-    const int cbase = (int)(t_beg + (int64_t)(ch & ~1) * CHUNK);
+    const int cbase = (int)(t_beg - t_seg + (int64_t)(ch & ~1) * CHUNK);      // train index inside the segment
     if ((ch & 1) == 1 || ch + 1 == n_chunks) {
 #pragma unroll
     for (int qb = 0; qb < QB; ++qb) {
@@ -218,7 +248,7 @@ __global__ __launch_bounds__(256) void k_knn2_u8(const uint8_t* __restrict__ q, 
     top2_insert((float)o2k, o2i, b1d, b1i, b2d, b2i);
     const int64_t qi = q0 + qb * 32 + l31;
     if (half == 0 && qi < nq) {
-      Cand* o = part + ((int64_t)split * nq + qi) * 2;
+      Cand* o = part + ((int64_t)split * total_out + qi + out_shift) * 2;
       o[0].d = b1i >= 0 ? b1d : 0.0f; o[0].i = b1i;      // d = d^2 (an exact integer below 2^24); k_merge_splits_u8 takes the root
       o[1].d = b2i >= 0 ? b2d : 0.0f; o[1].i = b2i;
     }
@@ -232,14 +262,26 @@ __global__ __launch_bounds__(256) void k_knn2_u8(const uint8_t* __restrict__ q, 
 template <int METRIC, int DIMW>   // DIMW = 32-bit words per row
 __global__ __launch_bounds__(256) void k_knn2_valu(const uint32_t* __restrict__ q, int64_t nq,
                                                    const uint32_t* __restrict__ t, int64_t nt, int nsplit,
-                                                   int64_t rows_per_split, Cand* __restrict__ part) {
+                                                   int64_t rows_per_split, const MatchWG* __restrict__ wg,
+                                                   int64_t total_out, Cand* __restrict__ part) {
   constexpr int TILE = 32;
   __shared__ uint32_t s_t[TILE * DIMW];
   const int tid = threadIdx.x;
-  const int split = blockIdx.x % nsplit;
-  const int64_t qi = (int64_t)(blockIdx.x / nsplit) * 256 + tid;
-  const int64_t t_beg = (int64_t)split * rows_per_split;
-  const int64_t t_end = (t_beg + rows_per_split) < nt ? (t_beg + rows_per_split) : nt;
+  int split;
+  int64_t qi, t_beg, t_end, t_seg = 0, out_shift = 0;
+  if (wg) {
+    const MatchWG r = wg[blockIdx.x];
+    split = r.split; t_beg = r.t_first; t_end = r.t_end; t_seg = r.t_seg;
+    qi = r.q_first + tid;
+    nq = r.q_end;
+    out_shift = r.out_first - r.q_first;
+  } else {
+    split = blockIdx.x % nsplit;
+    qi = (int64_t)(blockIdx.x / nsplit) * 256 + tid;
+    t_beg = (int64_t)split * rows_per_split;
+    t_end = (t_beg + rows_per_split) < nt ? (t_beg + rows_per_split) : nt;
+    total_out = nq;
+  }
   uint32_t qr[DIMW];
 #pragma unroll
   for (int k = 0; k < DIMW; ++k) qr[k] = (qi < nq) ? q[qi * DIMW + k] : 0u;
@@ -269,11 +311,11 @@ __global__ __launch_bounds__(256) void k_knn2_valu(const uint32_t* __restrict__ 
         for (int k = 0; k < DIMW; ++k) pc += __popc(qr[k] ^ s_t[r * DIMW + k]);
         dist = (float)pc;
       }
-      top2_insert(dist, (int)(base + r), b1d, b1i, b2d, b2i);
+      top2_insert(dist, (int)(base - t_seg + r), b1d, b1i, b2d, b2i);
     }
   }
   if (qi < nq) {
-    Cand* o = part + ((int64_t)split * nq + qi) * 2;
+    Cand* o = part + ((int64_t)split * total_out + qi + out_shift) * 2;
     o[0].d = b1i >= 0 ? b1d : 0.0f; o[0].i = b1i;
     o[1].d = b2i >= 0 ? b2d : 0.0f; o[1].i = b2i;
   }
@@ -318,7 +360,7 @@ __global__ __launch_bounds__(256) void k_merge_splits_u8(int64_t nq, int nsplit,
 // train row's exact integer d^2, its float32 root, top-2 by (root, index) - the rule of the oracle - over the
 // whole train set.  Rare by construction (see the header), so it is written for clarity, not speed.
 __global__ __launch_bounds__(256) void k_knn2_u8_rerank(const uint8_t* __restrict__ q, const uint8_t* __restrict__ t,
-                                                        int64_t nt, int dim, const int* __restrict__ fix_cnt,
+                                                        int64_t nt, int dim, MatchSegs segs, const int* __restrict__ fix_cnt,
                                                         const int* __restrict__ fix_list, int* __restrict__ idx1,
                                                         int* __restrict__ idx2, float* __restrict__ d1,
                                                         float* __restrict__ d2) {
@@ -328,13 +370,20 @@ __global__ __launch_bounds__(256) void k_knn2_u8_rerank(const uint8_t* __restric
   const int n_fix = *fix_cnt;
   const int words = dim >> 2;
   for (int f = blockIdx.x; f < n_fix; f += gridDim.x) {
-    const int qi = fix_list[f];
+    const int qi = fix_list[f];                        // output row
+    int64_t q_row = qi, t0 = 0, t1 = nt;
+    if (segs.n_seg > 0) {                              // segment of this output row: last s with out_ptr[s] <= qi
+      int lo = 0, hi = segs.n_seg - 1;
+      while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (segs.out_ptr[mid] <= qi) lo = mid; else hi = mid - 1; }
+      q_row = segs.q_beg[lo] + (qi - segs.out_ptr[lo]);
+      t0 = segs.t_beg[lo]; t1 = segs.t_end[lo];
+    }
     __syncthreads();
-    if (tid < words) s_q[tid] = ((const uint32_t*)(q + (int64_t)qi * dim))[tid];
+    if (tid < words) s_q[tid] = ((const uint32_t*)(q + q_row * dim))[tid];
     __syncthreads();
     float b1d = 3.0e38f, b2d = 3.0e38f; int b1i = -1, b2i = -1;
-    for (int64_t r = tid; r < nt; r += 256) {
-      const uint32_t* tr = (const uint32_t*)(t + r * dim);
+    for (int64_t r = tid; r < t1 - t0; r += 256) {
+      const uint32_t* tr = (const uint32_t*)(t + (t0 + r) * dim);
       int d2i = 0;
       for (int k = 0; k < words; ++k) {
         const uint32_t a = s_q[k], b = tr[k];
@@ -407,23 +456,105 @@ __global__ __launch_bounds__(256) void k_f32_to_u8(const float* __restrict__ src
 }
 
 // ------------------------------------------------------------------------------------ host
-static int pick_nsplit(int64_t nq, int64_t nt, int64_t q_per_wg) {
+static int pick_nsplit(int64_t nt) {
   // enough workgroups to fill 256 CUs a few times over, but splits of at least 512 train rows
   int ns = 8;
   while (ns > 1 && nt / ns < 512) ns >>= 1;
-  (void)nq; (void)q_per_wg;
   return ns;
+}
+
+// workspace carve (bytes): per-split candidates | train norms | query norms | ratio scratch | re-rank list + counter |
+// (batched only) workgroup records + segment table
+struct MatchWs {
+  Cand* part; int* tn; int* qn; int* fix_list; int* fix_cnt; char* plan; int64_t total;
+};
+static MatchWs match_ws_carve(char* ws, int64_t n_out, int64_t nt_rows, int64_t nq_rows, int64_t plan_bytes) {
+  MatchWs w;
+  int64_t off = 0;
+  w.part = (Cand*)(ws + off); off += align_up(8 * n_out * 2 * (int64_t)sizeof(Cand), 256);   // nsplit <= 8
+  w.tn = (int*)(ws + off); off += align_up(nt_rows * 4, 256);
+  w.qn = (int*)(ws + off); off += align_up(nq_rows * 4, 256);
+  off += align_up(((n_out + 255) / 256) * 8 + 64, 256);                                        // sfm_match_ratio's scratch may alias here
+  w.fix_list = (int*)(ws + off); off += align_up(n_out * 4, 256);
+  w.fix_cnt = (int*)(ws + off); off += 256;
+  w.plan = ws + off; off += align_up(plan_bytes, 256);
+  w.total = off + 1024;
+  return w;
 }
 
 extern "C" int sfm_match_workspace_bytes(int metric, int64_t nq, int64_t nt, int dim, int64_t* bytes) {
   if (!bytes || nq < 0 || nt < 0 || dim <= 0) return SFM_ERR_ARG;
   (void)metric;
-  int64_t b = 8 * nq * 2 * (int64_t)sizeof(Cand);   // per-split candidates (nsplit <= 8)
-  b = align_up(b, 256) + align_up(nt * 4, 256) + align_up(nq * 4, 256);
-  b += align_up(((nq + 255) / 256) * 8 + 64, 256);
-  b += align_up(nq * 4, 256) + 256;                  // re-rank list + its counter (L2 / uint8)
-  *bytes = b + 1024;
+  *bytes = match_ws_carve(nullptr, nq, nt, nq, 0).total;
   return SFM_OK;
+}
+
+// The distance + top-2 stage for one segment (wg == nullptr) or a planned batch.  n_out = output rows.
+static int match_launch(sfm_ctx* h, int metric, const void* q, int64_t nq_rows, const void* t, int64_t nt_rows, int dim,
+                        int nsplit, int64_t rps, const MatchWG* wg, unsigned grid, int64_t n_out, MatchSegs segs,
+                        const MatchWs& w, int32_t* idx1, int32_t* idx2, float* d1, float* d2) {
+  const uint8_t* q8 = (const uint8_t*)q; const uint8_t* t8 = (const uint8_t*)t;
+  const uint32_t* qq = (const uint32_t*)q; const uint32_t* tt = (const uint32_t*)t;
+  if (wg)   // segments choose their own number of splits: slots a segment does not use must read as "empty" (i = -1)
+    SFM_HIP(h, hipMemsetAsync(w.part, 0xFF, (size_t)8 * n_out * 2 * sizeof(Cand), h->stream));
+  if (metric == SFM_METRIC_L2_U8) {
+    hipLaunchKernelGGL(k_row_norm_u8, dim3(cdiv(nt_rows, 256)), dim3(256), 0, h->stream, t8, nt_rows, dim, 0x80, dim, w.tn);
+    hipLaunchKernelGGL(k_row_norm_u8, dim3(cdiv(nq_rows, 256)), dim3(256), 0, h->stream, q8, nq_rows, dim, 0x7F, 0, w.qn);
+    const char* qb_env = getenv("SFM_MATCH_QB");           // tuning knob (dim 128, single segment only): 4 query blocks per wave
+    const bool qb4 = !wg && (dim == 128) && qb_env && qb_env[0] == '4';
+    if (qb4) grid = cdiv(nq_rows, 4 * 4 * 32) * nsplit;
+    sfm_prof_begin(h, SFM_PROF_KNN);
+    if (qb4)
+      hipLaunchKernelGGL((k_knn2_u8<4, 4>), dim3(grid), dim3(256), 0, h->stream, q8, nq_rows, t8, nt_rows, w.tn, w.qn, nsplit, rps, wg, n_out, w.part);
+    else if (dim == 128)
+      hipLaunchKernelGGL((k_knn2_u8<4, 2>), dim3(grid), dim3(256), 0, h->stream, q8, nq_rows, t8, nt_rows, w.tn, w.qn, nsplit, rps, wg, n_out, w.part);
+    else if (dim == 64)
+      hipLaunchKernelGGL((k_knn2_u8<2, 2>), dim3(grid), dim3(256), 0, h->stream, q8, nq_rows, t8, nt_rows, w.tn, w.qn, nsplit, rps, wg, n_out, w.part);
+    else
+      hipLaunchKernelGGL((k_knn2_u8<1, 2>), dim3(grid), dim3(256), 0, h->stream, q8, nq_rows, t8, nt_rows, w.tn, w.qn, nsplit, rps, wg, n_out, w.part);
+    sfm_prof_end(h, SFM_PROF_KNN);
+    SFM_HIP(h, hipMemsetAsync(w.fix_cnt, 0, sizeof(int), h->stream));
+    hipLaunchKernelGGL(k_merge_splits_u8, dim3(cdiv(n_out, 256)), dim3(256), 0, h->stream, n_out, wg ? 8 : nsplit, w.part, idx1, idx2,
+                       d1, d2, w.fix_cnt, w.fix_list);
+    hipLaunchKernelGGL(k_knn2_u8_rerank, dim3(n_out < 2048 ? (unsigned)n_out : 2048u), dim3(256), 0, h->stream, q8, t8, nt_rows, dim,
+                       segs, w.fix_cnt, w.fix_list, idx1, idx2, d1, d2);
+  } else {
+#define VALU_LAUNCH(M, W) hipLaunchKernelGGL((k_knn2_valu<M, W>), dim3(grid), dim3(256), 0, h->stream, qq, nq_rows, tt, nt_rows, nsplit, rps, wg, n_out, w.part)
+    if (metric == SFM_METRIC_L2_F32) {
+      if (dim == 128) VALU_LAUNCH(1, 128);
+      else if (dim == 64) VALU_LAUNCH(1, 64);
+      else VALU_LAUNCH(1, 32);
+    } else {
+      if (dim == 32) VALU_LAUNCH(2, 8);
+      else if (dim == 64) VALU_LAUNCH(2, 16);
+      else VALU_LAUNCH(2, 4);
+    }
+#undef VALU_LAUNCH
+    hipLaunchKernelGGL(k_merge_splits, dim3(cdiv(n_out, 256)), dim3(256), 0, h->stream, n_out, wg ? 8 : nsplit, w.part, idx1, idx2, d1, d2);
+  }
+  SFM_LAUNCH_CHECK(h, "sfm_match_knn2");
+  return SFM_OK;
+}
+
+static int match_check_metric(sfm_ctx* h, int metric, int dim, const char* what) {
+  if (metric == SFM_METRIC_L2_U8) {
+    if (dim != 32 && dim != 64 && dim != 128) return sfm_fail(h, SFM_ERR_ARG, what, "L2_U8 needs dim 32, 64 or 128");
+  } else if (metric == SFM_METRIC_L2_F32) {
+    if (dim != 32 && dim != 64 && dim != 128) return sfm_fail(h, SFM_ERR_ARG, what, "L2_F32 supports dim 32, 64, 128");
+  } else if (metric == SFM_METRIC_HAMMING) {
+    if (dim != 16 && dim != 32 && dim != 64) return sfm_fail(h, SFM_ERR_ARG, what, "HAMMING supports dim 16, 32, 64 bytes");
+  } else {
+    return sfm_fail(h, SFM_ERR_ARG, what, "unknown metric");
+  }
+  return SFM_OK;
+}
+// rows of train data per split and queries per workgroup of the kernel a metric uses
+static void match_tiling(int metric, int64_t nt, int* nsplit, int64_t* rps) {
+  int ns = pick_nsplit(nt);
+  int64_t r = (nt + ns - 1) / ns;
+  if (metric == SFM_METRIC_L2_U8) r = align_up(r, 128);
+  *nsplit = (int)((nt + r - 1) / r);
+  *rps = r;
 }
 
 extern "C" int sfm_match_knn2(sfm_handle h, int metric, const void* q, int64_t nq, const void* t, int64_t nt,
@@ -433,70 +564,85 @@ extern "C" int sfm_match_knn2(sfm_handle h, int metric, const void* q, int64_t n
   if (!q || !t || !idx1 || !idx2 || !d1 || !d2 || !workspace) return sfm_fail(h, SFM_ERR_ARG, "sfm_match_knn2", "null pointer");
   if (nq < 1 || nt < 2) return sfm_fail(h, SFM_ERR_ARG, "sfm_match_knn2", "needs nq >= 1 and nt >= 2");
   if (nt > 0x7FFFFF00LL || nq > 0x7FFFFF00LL) return sfm_fail(h, SFM_ERR_ARG, "sfm_match_knn2", "too many rows");
-  int64_t need = 0;
-  sfm_match_workspace_bytes(metric, nq, nt, dim, &need);
-  if (workspace_bytes < need) return sfm_fail(h, SFM_ERR_WORKSPACE, "sfm_match_knn2", "workspace too small");
-  char* ws = (char*)workspace;
-  Cand* part = (Cand*)ws;
-  int64_t off = align_up(8 * nq * 2 * (int64_t)sizeof(Cand), 256);
-  int* tn = (int*)(ws + off); off += align_up(nt * 4, 256);
-  int* qn = (int*)(ws + off); off += align_up(nq * 4, 256);
-  off += align_up(((nq + 255) / 256) * 8 + 64, 256);
-  int* fix_list = (int*)(ws + off); off += align_up(nq * 4, 256);
-  int* fix_cnt = (int*)(ws + off);
-  int nsplit = 1;
-  if (metric == SFM_METRIC_L2_U8) {
-    if (dim != 32 && dim != 64 && dim != 128)
-      return sfm_fail(h, SFM_ERR_ARG, "sfm_match_knn2", "L2_U8 needs dim 32, 64 or 128");
-    constexpr int QB = 2;
-    const char* qb_env = getenv("SFM_MATCH_QB");           // tuning knob (dim 128 only): 4 query blocks per wave
-    const bool qb4 = (dim == 128) && qb_env && qb_env[0] == '4';
-    nsplit = pick_nsplit(nq, nt, 4 * QB * 32);
-    const int64_t rps = align_up((nt + nsplit - 1) / nsplit, 128);
-    nsplit = (int)((nt + rps - 1) / rps);
-    hipLaunchKernelGGL(k_row_norm_u8, dim3(cdiv(nt, 256)), dim3(256), 0, h->stream, (const uint8_t*)t, nt, dim, 0x80, dim, tn);
-    hipLaunchKernelGGL(k_row_norm_u8, dim3(cdiv(nq, 256)), dim3(256), 0, h->stream, (const uint8_t*)q, nq, dim, 0x7F, 0, qn);
-    const unsigned grid = cdiv(nq, 4 * (qb4 ? 4 : QB) * 32) * nsplit;
-    sfm_prof_begin(h, SFM_PROF_KNN);
-    if (qb4)
-      hipLaunchKernelGGL((k_knn2_u8<4, 4>), dim3(grid), dim3(256), 0, h->stream, (const uint8_t*)q, nq, (const uint8_t*)t, nt, tn, qn, nsplit, rps, part);
-    else if (dim == 128)
-      hipLaunchKernelGGL((k_knn2_u8<4, QB>), dim3(grid), dim3(256), 0, h->stream, (const uint8_t*)q, nq, (const uint8_t*)t, nt, tn, qn, nsplit, rps, part);
-    else if (dim == 64)
-      hipLaunchKernelGGL((k_knn2_u8<2, QB>), dim3(grid), dim3(256), 0, h->stream, (const uint8_t*)q, nq, (const uint8_t*)t, nt, tn, qn, nsplit, rps, part);
-    else
-      hipLaunchKernelGGL((k_knn2_u8<1, QB>), dim3(grid), dim3(256), 0, h->stream, (const uint8_t*)q, nq, (const uint8_t*)t, nt, tn, qn, nsplit, rps, part);
-    sfm_prof_end(h, SFM_PROF_KNN);
-    SFM_HIP(h, hipMemsetAsync(fix_cnt, 0, sizeof(int), h->stream));
-    hipLaunchKernelGGL(k_merge_splits_u8, dim3(cdiv(nq, 256)), dim3(256), 0, h->stream, nq, nsplit, part, idx1, idx2, d1, d2,
-                       fix_cnt, fix_list);
-    hipLaunchKernelGGL(k_knn2_u8_rerank, dim3(nq < 2048 ? (unsigned)nq : 2048u), dim3(256), 0, h->stream, (const uint8_t*)q,
-                       (const uint8_t*)t, nt, dim, fix_cnt, fix_list, idx1, idx2, d1, d2);
-    SFM_LAUNCH_CHECK(h, "sfm_match_knn2");
-    return SFM_OK;
-  } else if (metric == SFM_METRIC_L2_F32 || metric == SFM_METRIC_HAMMING) {
-    nsplit = pick_nsplit(nq, nt, 256);
-    const int64_t rps = (nt + nsplit - 1) / nsplit;
-    nsplit = (int)((nt + rps - 1) / rps);
-    const unsigned grid = cdiv(nq, 256) * nsplit;
-    const uint32_t* qq = (const uint32_t*)q; const uint32_t* tt = (const uint32_t*)t;
-    if (metric == SFM_METRIC_L2_F32) {
-      if (dim == 128) hipLaunchKernelGGL((k_knn2_valu<1, 128>), dim3(grid), dim3(256), 0, h->stream, qq, nq, tt, nt, nsplit, rps, part);
-      else if (dim == 64) hipLaunchKernelGGL((k_knn2_valu<1, 64>), dim3(grid), dim3(256), 0, h->stream, qq, nq, tt, nt, nsplit, rps, part);
-      else if (dim == 32) hipLaunchKernelGGL((k_knn2_valu<1, 32>), dim3(grid), dim3(256), 0, h->stream, qq, nq, tt, nt, nsplit, rps, part);
-      else return sfm_fail(h, SFM_ERR_ARG, "sfm_match_knn2", "L2_F32 supports dim 32, 64, 128");
-    } else {
-      if (dim == 32) hipLaunchKernelGGL((k_knn2_valu<2, 8>), dim3(grid), dim3(256), 0, h->stream, qq, nq, tt, nt, nsplit, rps, part);
-      else if (dim == 64) hipLaunchKernelGGL((k_knn2_valu<2, 16>), dim3(grid), dim3(256), 0, h->stream, qq, nq, tt, nt, nsplit, rps, part);
-      else if (dim == 16) hipLaunchKernelGGL((k_knn2_valu<2, 4>), dim3(grid), dim3(256), 0, h->stream, qq, nq, tt, nt, nsplit, rps, part);
-      else return sfm_fail(h, SFM_ERR_ARG, "sfm_match_knn2", "HAMMING supports dim 16, 32, 64 bytes");
-    }
-  } else {
-    return sfm_fail(h, SFM_ERR_ARG, "sfm_match_knn2", "unknown metric");
+  int rc = match_check_metric(h, metric, dim, "sfm_match_knn2"); if (rc) return rc;
+  const MatchWs w = match_ws_carve((char*)workspace, nq, nt, nq, 0);
+  if (workspace_bytes < w.total) return sfm_fail(h, SFM_ERR_WORKSPACE, "sfm_match_knn2", "workspace too small");
+  int nsplit; int64_t rps;
+  match_tiling(metric, nt, &nsplit, &rps);
+  const unsigned grid = cdiv(nq, 256) * nsplit;
+  MatchSegs none = {nullptr, nullptr, nullptr, nullptr, 0};
+  return match_launch(h, metric, q, nq, t, nt, dim, nsplit, rps, nullptr, grid, nq, none, w, idx1, idx2, d1, d2);
+}
+
+// ---- batched: every image pair of a preprocessing step in one launch
+static void plan_segments(int metric, int32_t n_seg, const int64_t* q_beg, const int64_t* q_end, const int64_t* t_beg,
+                          const int64_t* t_end, std::vector<MatchWG>* wgs, std::vector<int64_t>* out_ptr) {
+  out_ptr->assign((size_t)n_seg + 1, 0);
+  for (int s = 0; s < n_seg; ++s) {
+    const int64_t nq = q_end[s] - q_beg[s], nt = t_end[s] - t_beg[s];
+    (*out_ptr)[s + 1] = (*out_ptr)[s] + nq;
+    if (nq <= 0) continue;
+    int nsplit; int64_t rps;
+    match_tiling(metric, nt, &nsplit, &rps);
+    for (int64_t qb = 0; qb < nq; qb += 256)
+      for (int sp = 0; sp < nsplit; ++sp) {          // consecutive workgroups = consecutive splits: one XCD per split as in the single-pair launch
+        MatchWG r;
+        r.q_first = q_beg[s] + qb; r.q_end = q_end[s];
+        r.t_first = t_beg[s] + sp * rps; r.t_end = (r.t_first + rps) < t_end[s] ? (r.t_first + rps) : t_end[s];
+        r.t_seg = t_beg[s]; r.out_first = (*out_ptr)[s] + qb; r.split = sp; r.pad = 0;
+        wgs->push_back(r);
+      }
   }
-  hipLaunchKernelGGL(k_merge_splits, dim3(cdiv(nq, 256)), dim3(256), 0, h->stream, nq, nsplit, part, idx1, idx2, d1, d2);
-  SFM_LAUNCH_CHECK(h, "sfm_match_knn2");
+}
+
+extern "C" int sfm_match_batched_workspace_bytes(int metric, int32_t n_seg, const int64_t* q_beg_host, const int64_t* q_end_host,
+                                                 const int64_t* t_beg_host, const int64_t* t_end_host, int64_t nq_rows,
+                                                 int64_t nt_rows, int64_t* n_out_host, int64_t* bytes_host) {
+  if (n_seg < 1 || !q_beg_host || !q_end_host || !t_beg_host || !t_end_host || !n_out_host || !bytes_host) return SFM_ERR_ARG;
+  std::vector<MatchWG> wgs; std::vector<int64_t> out_ptr;
+  plan_segments(metric, n_seg, q_beg_host, q_end_host, t_beg_host, t_end_host, &wgs, &out_ptr);
+  *n_out_host = out_ptr[n_seg];
+  const int64_t plan_bytes = (int64_t)wgs.size() * sizeof(MatchWG) + 4 * ((int64_t)n_seg + 1) * 8 + 256;
+  *bytes_host = match_ws_carve(nullptr, out_ptr[n_seg] > 0 ? out_ptr[n_seg] : 1, nt_rows, nq_rows, plan_bytes).total;
   return SFM_OK;
+}
+
+extern "C" int sfm_match_knn2_batched(sfm_handle h, int metric, const void* q, int64_t nq_rows, const void* t, int64_t nt_rows,
+                                      int dim, int32_t n_seg, const int64_t* q_beg_host, const int64_t* q_end_host,
+                                      const int64_t* t_beg_host, const int64_t* t_end_host, int32_t* idx1, int32_t* idx2,
+                                      float* d1, float* d2, int64_t* out_ptr_device, void* workspace, int64_t workspace_bytes) {
+  if (!h) return SFM_ERR_ARG;
+  if (!q || !t || !idx1 || !idx2 || !d1 || !d2 || !workspace || !q_beg_host || !q_end_host || !t_beg_host || !t_end_host || n_seg < 1)
+    return sfm_fail(h, SFM_ERR_ARG, "sfm_match_knn2_batched", "null pointer / no segments");
+  int rc = match_check_metric(h, metric, dim, "sfm_match_knn2_batched"); if (rc) return rc;
+  if (nq_rows > 0x7FFFFF00LL || nt_rows > 0x7FFFFF00LL) return sfm_fail(h, SFM_ERR_ARG, "sfm_match_knn2_batched", "too many rows");
+  for (int s = 0; s < n_seg; ++s) {
+    if (q_beg_host[s] < 0 || q_end_host[s] < q_beg_host[s] || q_end_host[s] > nq_rows || t_beg_host[s] < 0 || t_end_host[s] > nt_rows)
+      return sfm_fail(h, SFM_ERR_ARG, "sfm_match_knn2_batched", "segment outside the descriptor arrays");
+    if (q_end_host[s] > q_beg_host[s] && t_end_host[s] - t_beg_host[s] < 2)
+      return sfm_fail(h, SFM_ERR_ARG, "sfm_match_knn2_batched", "a segment with queries needs at least 2 train rows");
+  }
+  std::vector<MatchWG> wgs; std::vector<int64_t> out_ptr;
+  plan_segments(metric, n_seg, q_beg_host, q_end_host, t_beg_host, t_end_host, &wgs, &out_ptr);
+  const int64_t n_out = out_ptr[n_seg];
+  if (n_out < 1) return sfm_fail(h, SFM_ERR_ARG, "sfm_match_knn2_batched", "no query rows");
+  const int64_t wg_bytes = (int64_t)wgs.size() * sizeof(MatchWG), seg_bytes = ((int64_t)n_seg + 1) * 8;
+  const MatchWs w = match_ws_carve((char*)workspace, n_out, nt_rows, nq_rows, wg_bytes + 4 * seg_bytes + 256);
+  if (workspace_bytes < w.total) return sfm_fail(h, SFM_ERR_WORKSPACE, "sfm_match_knn2_batched", "workspace too small");
+  // plan -> device: workgroup records, then q_beg | t_beg | t_end | out_ptr
+  char* dp = w.plan;
+  int64_t* d_seg = (int64_t*)(dp + align_up(wg_bytes, 256));
+  SFM_HIP(h, hipMemcpyAsync(dp, wgs.data(), (size_t)wg_bytes, hipMemcpyHostToDevice, h->stream));
+  SFM_HIP(h, hipMemcpyAsync(d_seg, q_beg_host, (size_t)n_seg * 8, hipMemcpyHostToDevice, h->stream));
+  SFM_HIP(h, hipMemcpyAsync(d_seg + (n_seg + 1), t_beg_host, (size_t)n_seg * 8, hipMemcpyHostToDevice, h->stream));
+  SFM_HIP(h, hipMemcpyAsync(d_seg + 2 * (n_seg + 1), t_end_host, (size_t)n_seg * 8, hipMemcpyHostToDevice, h->stream));
+  SFM_HIP(h, hipMemcpyAsync(d_seg + 3 * (n_seg + 1), out_ptr.data(), (size_t)seg_bytes, hipMemcpyHostToDevice, h->stream));
+  if (out_ptr_device)
+    SFM_HIP(h, hipMemcpyAsync(out_ptr_device, out_ptr.data(), (size_t)seg_bytes, hipMemcpyHostToDevice, h->stream));
+  SFM_HIP(h, hipStreamSynchronize(h->stream));          // the host vectors are pageable: the copies must have left them
+  MatchSegs segs = {d_seg, d_seg + (n_seg + 1), d_seg + 2 * (n_seg + 1), d_seg + 3 * (n_seg + 1), n_seg};
+  return match_launch(h, metric, q, nq_rows, t, nt_rows, dim, 1, 0, (const MatchWG*)dp, (unsigned)wgs.size(), n_out, segs, w,
+                      idx1, idx2, d1, d2);
 }
 
 extern "C" int sfm_match_ratio(sfm_handle h, int64_t nq, const int32_t* idx1, const float* d1, const float* d2,
@@ -514,6 +660,47 @@ extern "C" int sfm_match_ratio(sfm_handle h, int64_t nq, const int32_t* idx1, co
   hipLaunchKernelGGL(k_ratio_scatter, dim3(nblk), dim3(256), 0, h->stream, nq, idx1, d1, d2, ratio, blk_off,
                      query_idx, train_idx, dist);
   SFM_LAUNCH_CHECK(h, "sfm_match_ratio");
+  return SFM_OK;
+}
+
+// after the compaction of a batch: where each segment's matches begin, and query indices relative to their segment
+__global__ __launch_bounds__(256) void k_seg_split(int64_t n_out, int n_seg, const int64_t* __restrict__ out_ptr,
+                                                   const int64_t* __restrict__ n_matches, int* __restrict__ query_idx,
+                                                   int64_t* __restrict__ seg_match_ptr) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t M = *n_matches;
+  if (i <= n_seg) {                       // first match whose output row is >= out_ptr[i]   (query_idx is ascending)
+    const int64_t key = out_ptr[i];
+    int64_t lo = 0, hi = M;
+    while (lo < hi) { const int64_t mid = (lo + hi) >> 1; if (query_idx[mid] < key) lo = mid + 1; else hi = mid; }
+    seg_match_ptr[i] = lo;
+  }
+}
+__global__ __launch_bounds__(256) void k_seg_localise(int n_seg, const int64_t* __restrict__ out_ptr,
+                                                      const int64_t* __restrict__ n_matches, int* __restrict__ query_idx) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= *n_matches) return;
+  const int64_t row = query_idx[i];
+  int lo = 0, hi = n_seg - 1;             // last segment with out_ptr[s] <= row
+  while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (out_ptr[mid] <= row) lo = mid; else hi = mid - 1; }
+  query_idx[i] = (int)(row - out_ptr[lo]);
+}
+
+extern "C" int sfm_match_ratio_batched(sfm_handle h, int64_t n_out, int32_t n_seg, const int64_t* out_ptr, const int32_t* idx1,
+                                       const float* d1, const float* d2, double ratio, int32_t* query_idx, int32_t* train_idx,
+                                       float* dist, int64_t* seg_match_ptr, void* workspace, int64_t workspace_bytes) {
+  if (!h) return SFM_ERR_ARG;
+  if (!out_ptr || !seg_match_ptr || n_seg < 1) return sfm_fail(h, SFM_ERR_ARG, "sfm_match_ratio_batched", "bad argument");
+  const int64_t need = (int64_t)cdiv(n_out, 256) * 8 + 64;
+  if (workspace_bytes < need) return sfm_fail(h, SFM_ERR_WORKSPACE, "sfm_match_ratio_batched", "workspace too small");
+  int64_t* n_matches = (int64_t*)((char*)workspace + align_up((int64_t)cdiv(n_out, 256) * 8, 8));
+  int rc = sfm_match_ratio(h, n_out, idx1, d1, d2, ratio, query_idx, train_idx, dist, n_matches, workspace, (int64_t)cdiv(n_out, 256) * 8);
+  if (rc) return rc;
+  // the split reads the global (output-row) query indices: it must run before they are made segment-relative
+  hipLaunchKernelGGL(k_seg_split, dim3(cdiv((int64_t)n_seg + 1, 256)), dim3(256), 0, h->stream, n_out, n_seg, out_ptr, n_matches,
+                     query_idx, seg_match_ptr);
+  hipLaunchKernelGGL(k_seg_localise, dim3(cdiv(n_out, 256)), dim3(256), 0, h->stream, n_seg, out_ptr, n_matches, query_idx);
+  SFM_LAUNCH_CHECK(h, "sfm_match_ratio_batched");
   return SFM_OK;
 }
 

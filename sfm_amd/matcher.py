@@ -138,6 +138,96 @@ def match_arrays(desc1, desc2, ratio=0.75, metric="auto", device=0):
     return q.cpu().numpy(), t.cpu().numpy(), d.cpu().numpy()
 
 
+def _prepare_sets(descs, metric, dev, h):
+    """Descriptor sets of several images -> one device array (rows back to back), its row offsets and the metric code.
+    Same dtype rules as knn2: float32 sets whose values are all integers in [0,255] go to the exact uint8 path."""
+    import torch
+    arrs = [np.ascontiguousarray(d) for d in descs]
+    if not arrs:
+        raise ValueError("no descriptor sets")
+    dim = arrs[0].shape[1]
+    if any(a.ndim != 2 or a.shape[1] != dim or a.dtype != arrs[0].dtype for a in arrs):
+        raise ValueError("descriptor sets must be [n, dim] arrays of one dtype and dim")
+    ptr = np.zeros(len(arrs) + 1, dtype=np.int64)
+    np.cumsum([a.shape[0] for a in arrs], out=ptr[1:])
+    allrows = torch.from_numpy(np.concatenate(arrs, axis=0)).to(dev)
+    metric = _resolve_metric(allrows, allrows, metric)
+    if metric == "hamming":
+        if allrows.dtype != torch.uint8:
+            raise ValueError("hamming needs uint8 descriptors")
+        return allrows, ptr, _lib.METRIC_HAMMING, dim
+    if allrows.dtype == torch.uint8:
+        if dim in (32, 64, 128):
+            return allrows, ptr, _lib.METRIC_L2_U8, dim
+        return allrows.float(), ptr, _lib.METRIC_L2_F32, dim
+    allrows = allrows.float()
+    if dim in (32, 64, 128):
+        flag = torch.ones(1, dtype=torch.int32, device=dev)
+        a8 = torch.empty(allrows.shape, dtype=torch.uint8, device=dev)
+        h.call("sfm_match_f32_to_u8", C.c_void_p(allrows.data_ptr()), allrows.numel(), C.c_void_p(a8.data_ptr()),
+               C.c_void_p(flag.data_ptr()))
+        if int(flag.item()) == 1:
+            return a8, ptr, _lib.METRIC_L2_U8, dim
+    return allrows, ptr, _lib.METRIC_L2_F32, dim
+
+
+def match_pairs(descs, pairs, ratio=0.75, metric="auto", device=0):
+    """match_features for MANY image pairs in one launch (sfm_match_knn2_batched + sfm_match_ratio_batched).
+
+    descs: list of per-image descriptor arrays; pairs: list of (i, j) = match image i's descriptors (queries)
+    against image j's (train), exactly what the reference does once per pair in its serial loop
+    (find_matches.py:329-350, call at :272).  Returns one (queryIdx, trainIdx, distance) triple of NumPy arrays
+    per pair, each bit-identical to match_arrays(descs[i], descs[j]).  Pairs with an empty side yield empty
+    arrays; a pair whose train image has exactly one descriptor raises like the reference's unpacking (:151)."""
+    import torch
+    empty = (np.zeros(0, np.int32), np.zeros(0, np.int32), np.zeros(0, np.float32))
+    pairs = [(int(i), int(j)) for i, j in pairs]
+    sizes = [int(np.asarray(d).shape[0]) for d in descs]
+    for i, j in pairs:
+        if sizes[i] > 0 and sizes[j] == 1:
+            raise ValueError("not enough values to unpack (expected 2, got 1)")
+    live = [s for s, (i, j) in enumerate(pairs) if sizes[i] > 0 and sizes[j] >= 2]
+    out = [empty] * len(pairs)
+    if not live:
+        return out
+    h = _lib.get_handle(device)
+    dev = torch.device("cuda", device)
+    rows, ptr, code, dim = _prepare_sets(descs, metric, dev, h)
+    n_seg = len(live)
+    q_beg = np.array([ptr[pairs[s][0]] for s in live], dtype=np.int64)
+    q_end = np.array([ptr[pairs[s][0] + 1] for s in live], dtype=np.int64)
+    t_beg = np.array([ptr[pairs[s][1]] for s in live], dtype=np.int64)
+    t_end = np.array([ptr[pairs[s][1] + 1] for s in live], dtype=np.int64)
+    hp = lambda a: C.c_void_p(a.ctypes.data)
+    n_out, need = C.c_int64(), C.c_int64()
+    n_rows = int(rows.shape[0])
+    h.check(h.lib.sfm_match_batched_workspace_bytes(code, n_seg, hp(q_beg), hp(q_end), hp(t_beg), hp(t_end), n_rows, n_rows,
+                                                    C.byref(n_out), C.byref(need)), "sfm_match_batched_workspace_bytes")
+    n = n_out.value
+    ws = torch.empty(need.value, dtype=torch.uint8, device=dev)
+    idx1 = torch.empty(n, dtype=torch.int32, device=dev)
+    idx2 = torch.empty(n, dtype=torch.int32, device=dev)
+    d1 = torch.empty(n, dtype=torch.float32, device=dev)
+    d2 = torch.empty(n, dtype=torch.float32, device=dev)
+    out_ptr = torch.empty(n_seg + 1, dtype=torch.int64, device=dev)
+    dp = lambda t: C.c_void_p(t.data_ptr())
+    h.call("sfm_match_knn2_batched", code, dp(rows), n_rows, dp(rows), n_rows, dim, n_seg, hp(q_beg), hp(q_end), hp(t_beg),
+           hp(t_end), dp(idx1), dp(idx2), dp(d1), dp(d2), dp(out_ptr), dp(ws), need.value)
+    qi = torch.empty(n, dtype=torch.int32, device=dev)
+    ti = torch.empty(n, dtype=torch.int32, device=dev)
+    dd = torch.empty(n, dtype=torch.float32, device=dev)
+    seg_ptr = torch.empty(n_seg + 1, dtype=torch.int64, device=dev)
+    h.call("sfm_match_ratio_batched", n, n_seg, dp(out_ptr), dp(idx1), dp(d1), dp(d2), C.c_double(ratio), dp(qi), dp(ti),
+           dp(dd), dp(seg_ptr), dp(ws), need.value)
+    sp = seg_ptr.cpu().numpy()
+    m = int(sp[-1])
+    qh, th, dh = qi[:m].cpu().numpy(), ti[:m].cpu().numpy(), dd[:m].cpu().numpy()
+    for k, s in enumerate(live):
+        a, b = int(sp[k]), int(sp[k + 1])
+        out[s] = (qh[a:b].copy(), th[a:b].copy(), dh[a:b].copy())
+    return out
+
+
 class ImageMatcher(VerificationMixin):
     """`match_features` with the reference's call shape (find_matches.py:141).  The in-tree
     reference matches ORB bit strings with NORM_HAMMING and ratio 0.75; its shipped results come
@@ -152,3 +242,9 @@ class ImageMatcher(VerificationMixin):
     def match_features(self, desc1, desc2):
         q, t, d = match_arrays(desc1, desc2, self.ratio, self.metric, self.device)
         return [DMatch(a, b, c) for a, b, c in zip(q.tolist(), t.tolist(), d.tolist())]
+
+    def match_features_batched(self, descs, pairs):
+        """match_features(descs[i], descs[j]) for every (i, j) of `pairs` in one launch: the list the reference's
+        pair loop (find_matches.py:329-350) would have collected call by call."""
+        return [[DMatch(a, b, c) for a, b, c in zip(q.tolist(), t.tolist(), d.tolist())]
+                for q, t, d in match_pairs(descs, pairs, self.ratio, self.metric, self.device)]

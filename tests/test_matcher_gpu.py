@@ -176,3 +176,57 @@ def test_full_size_50k_all_rows(gpu_ready):
     assert np.array_equal(q, np.nonzero(keep)[0])
     rq, rt, rd = mo.ratio_filter(got[0], got[2], got[3], 0.75)
     assert np.array_equal(t, rt) and np.array_equal(d.cpu().numpy(), rd)
+
+
+# ------------------------------------------------------------------ batched (segmented) matching
+def _image_sets(sizes, seed, kind="sift", dim=128):
+    from sfm_amd import synth
+    rng = np.random.default_rng(seed)
+    if kind == "orb":
+        return [rng.integers(0, 256, size=(n, 32), dtype=np.uint8) for n in sizes]
+    base, _ = synth.make_descriptors(max(sizes) + 50, 2, seed=seed, dim=dim)
+    sets = []
+    for n in sizes:      # images share descriptors (noisy copies) so that the ratio test keeps a good fraction
+        rows = base[rng.permutation(base.shape[0])[:n]] + np.rint(rng.normal(0, 5.0, size=(n, dim))).astype(np.float32)
+        sets.append(np.clip(rows, 0, 255).astype(np.float32))
+    return sets
+
+
+@pytest.mark.parametrize("kind,as_u8", [("sift", False), ("sift", True), ("orb", True)])
+def test_batched_pairs_equal_per_pair_calls(gpu_ready, kind, as_u8):
+    """All image pairs of a preprocessing step in one launch (find_matches.py:329-350 loops over them serially):
+    bit-identical to one match_features call per pair - ragged image sizes incl. one above a split boundary,
+    an empty image, the same image on both sides, SIFT-like (float32 and uint8) and ORB (Hamming) descriptors."""
+    from sfm_amd.matcher import ImageMatcher, match_arrays, match_pairs
+    sizes = [300, 511, 2, 257, 0, 4500, 128, 1000]
+    sets = _image_sets(sizes, seed=5, kind=kind)
+    if as_u8:
+        sets = [s.astype(np.uint8) for s in sets]
+    pairs = [(i, j) for i in range(len(sizes)) for j in range(i + 1, len(sizes))] + [(3, 3), (5, 0), (6, 1)]
+    got = match_pairs(sets, pairs)
+    assert len(got) == len(pairs)
+    n_matches = 0
+    for (i, j), (q, t, d) in zip(pairs, got):
+        rq, rt, rd = match_arrays(sets[i], sets[j]) if sizes[i] and sizes[j] else (np.zeros(0, np.int32),) * 2 + (np.zeros(0, np.float32),)
+        assert np.array_equal(q, rq) and np.array_equal(t, rt) and np.array_equal(d, rd), (i, j)
+        n_matches += len(q)
+    assert n_matches > 200
+    ms = ImageMatcher().match_features_batched(sets, pairs[:3])
+    assert [[(m.queryIdx, m.trainIdx) for m in l] for l in ms] == [list(zip(q.tolist(), t.tolist())) for q, t, _ in got[:3]]
+
+
+def test_batched_pairs_vs_oracle_and_degenerate_sizes(gpu_ready):
+    from oracle import matcher_oracle as mo
+    from sfm_amd.matcher import match_pairs
+    sets = _image_sets([200, 333, 1, 640], seed=11)
+    got = match_pairs(sets, [(0, 1), (1, 3), (3, 0)])
+    for (i, j), (q, t, d) in zip([(0, 1), (1, 3), (3, 0)], got):
+        rq, rt, rd = mo.match_features(sets[i], sets[j], 0.75, "l2")
+        assert np.array_equal(q, rq) and np.array_equal(t, rt) and np.array_equal(d, rd)
+    with pytest.raises(ValueError, match="not enough values to unpack"):      # train image with ONE descriptor (find_matches.py:151)
+        match_pairs(sets, [(0, 1), (0, 2)])
+    far_q, far_t = far_apart_sets(40, 600, 128, seed=3)                        # re-rank path inside a batch
+    ordinary = _image_sets([300], seed=2)[0].astype(np.uint8)
+    got = match_pairs([far_q, far_t, ordinary], [(2, 2), (0, 1), (2, 1)], ratio=2.0)     # ratio 2: every query row is kept
+    ref = mo.knn2(far_q, far_t, "l2")
+    assert np.array_equal(got[1][1], ref[0]) and np.array_equal(got[1][2], ref[2]) and len(got[1][0]) == 40
