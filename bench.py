@@ -45,6 +45,7 @@ def parse():
     ap.add_argument("--no-d6", action="store_true")
     ap.add_argument("--no-mixed", action="store_true")
     ap.add_argument("--no-dropin", action="store_true")
+    ap.add_argument("--no-pcg", action="store_true")
     ap.add_argument("--no-driver-rows", action="store_true")
     return ap.parse_args()
 
@@ -107,9 +108,10 @@ def main():
     n_obs_total = sc.n_obs
     n_sys = C * d
 
-    def fixed_schedule_run(cam_dim, precision, profile):
+    def fixed_schedule_run(cam_dim, precision, profile, solver="dense"):
         """W warm-up + K timed outer iterations of the trust-region loop (library side, termination tests off)."""
-        be = GpuBA(sc.cams0[:, :cam_dim], pts0, ci, pi, uv, synth.K_REF, device=local_rank, comm=comm, precision=precision)
+        be = GpuBA(sc.cams0[:, :cam_dim], pts0, ci, pi, uv, synth.K_REF, device=local_rank, comm=comm, precision=precision,
+                   solver=solver)
         st = be.trf_begin(max_nfev=2 ** 31 - 1, check_tolerances=False)
         cost0 = st.result().cost
         for _ in range(args.warmup):
@@ -129,8 +131,9 @@ def main():
             prof = be.h.profile()
             be.h.set_profiling(False)
         r1 = st.result()
+        cg_iters = be.cg_iters
         st.close()
-        out = {"elapsed": elapsed, "value": args.steps / elapsed, "ms_per_step": elapsed / args.steps * 1e3,
+        out = {"cg_iters": cg_iters, "elapsed": elapsed, "value": args.steps / elapsed, "ms_per_step": elapsed / args.steps * 1e3,
                "damped_solves": r1.n_solves - r0.n_solves, "trial_steps": r1.nfev - r0.nfev, "cost_start": cost0,
                "cost_end": r1.cost, "n_pairs": be.n_pairs, "n_obs_local": be.N, "prof": prof}
         del st, be
@@ -208,6 +211,14 @@ def main():
         ba_mixed = brief(rm, "same scene and schedule, SFM_BA_MIXED: Jacobian rows stored in float32, every sum / W L^-T / S / "
                              "solve in float64 (opt-in; the headline stays float64)")
         ba_mixed["kernels_us"] = {k: round(v[0] / v[1] * 1e3, 2) for k, v in rm["prof"].items() if v[1] > 0}
+
+    ba_pcg = None
+    if not args.no_pcg:
+        rp = fixed_schedule_run(d, "fp64", True, solver="pcg")
+        ba_pcg = brief(rp, "same scene and schedule, camera system solved by PCG on the implicit Schur complement "
+                           "(sfm_ba_solve_pcg: S never formed; rtol 1e-13): the multi-rank / many-camera route")
+        ba_pcg["cg_iterations_total_incl_warmup"] = rp["cg_iters"]
+        ba_pcg["kernels_us"] = {k: round(v[0] / v[1] * 1e3, 2) for k, v in rp["prof"].items() if v[1] > 0}
 
     # ------------------------------------------------------------------ end-to-end drop-in call (N = 1 only)
     # wall clock of ONE StructureFromMotion.bundle_adjust() with the reference's settings (ftol = xtol = 1e-4,
@@ -349,7 +360,7 @@ def main():
                    "cost_end": main["cost_end"], "solves_per_s": main["damped_solves"] / elapsed, "kernels": kernels,
                    "kernels_note": "HIP-event times from a second pass of the same schedule; the timed pass carries no events",
                    "loop": "sfm_ba_trf_outer (library-side trust-region loop)"},
-            "ba_cam_dim6": ba_d6, "ba_mixed_precision": ba_mixed, "dropin": dropin,
+            "ba_cam_dim6": ba_d6, "ba_mixed_precision": ba_mixed, "ba_pcg_solver": ba_pcg, "dropin": dropin,
             "roofline": roofline, "rooflines": roofs, "cpu_baseline": cpu_baseline, "matcher": matcher,
             "driver_rows": driver_rows,
         }

@@ -137,6 +137,11 @@ typedef struct {
 
 typedef struct sfm_ba_prob* sfm_ba_problem;    /* opaque; owns its index structure (device memory) */
 
+/* Multi-rank hook (points sharded over GPUs, cameras replicated): all-reduce `count` doubles at device pointer
+ * `data` (inside the bound workspace) in place across the ranks: op 0 = SUM, 1 = MAX.  Return 0 on success.
+ * NULL = single rank. */
+typedef int (*sfm_reduce_fn)(void* user, void* data, int64_t count, int op);
+
 /* Validates the indices and builds, ON THE DEVICE, everything the kernels need besides the arrays above:
  * per-point / per-camera observation lists, the camera-pair lists of the Schur complement and their split
  * into work items (sfm_ba_structure shows them).  Synchronises the stream (sizes are data-dependent).
@@ -183,6 +188,7 @@ typedef struct {
   int64_t pc_off, pp_off;           /* camera / point part of p = -(H + alpha I)^-1 g */
   int64_t scalars_off;              /* 16 doubles, see SFM_SC_* */
   int64_t G_off;                    /* [n_obs][3][cam_dim] */
+  int64_t cg_Ap_off, cg_M_off;      /* sfm_ba_solve_pcg: S p [n] and the block-Jacobi blocks [n_cams][cam_dim][cam_dim] (this rank's partial sums) SUM */
 } sfm_ba_layout;
 
 enum { SFM_SC_COST = 0, SFM_SC_GNORM2 = 1, SFM_SC_GINF = 2, SFM_SC_PNORM2 = 3, SFM_SC_PQ = 4,
@@ -222,6 +228,17 @@ int sfm_ba_unpack_system(sfm_handle h, sfm_ba_problem p);
 int sfm_ba_schur_solve(sfm_handle h, sfm_ba_problem p, double alpha, int want_q); /* chol, p_c, p_p; -> reduce_q (partial) */
 int sfm_ba_finish_solve(sfm_handle h, sfm_ba_problem p, int want_q);              /* scalars PNORM2 (and PQ) */
 
+/* The same damped solve WITHOUT forming or factoring S: conjugate gradients on the implicit Schur complement
+ * S v = (B + alpha I) v - W (C + alpha I)^-1 W^T v (two passes over G per product), preconditioned with the exact
+ * d x d diagonal blocks of S.  One call = schur_build + schur_solve + finish_solve: afterwards pc / pp hold the step
+ * and the scalars PNORM2 (and PQ when want_q) are set; SFM_SC_CHOL_FAIL != 0 when S or a block is not positive
+ * definite.  Stops when ||r|| <= rtol ||r_0|| (checked every 8 iterations) or after max_iter iterations per system
+ * (want_q solves two).  Multi-rank: `reduce` sums, per call, the right-hand side and the diagonal blocks once and
+ * ONE vector of n doubles per iteration - against n(n+1)/2 + n doubles and a replicated factorisation on the dense
+ * route; meant for many cameras (BASELINE config 5) and for scaling over GPUs.  iters_host: CG iterations spent. */
+int sfm_ba_solve_pcg(sfm_handle h, sfm_ba_problem p, double alpha, int want_q, double rtol, int32_t max_iter,
+                     sfm_reduce_fn reduce, void* reduce_user, int32_t* iters_host);
+
 /* s = scale * p;  x_new = x + s;  partial sums for the predicted reduction and cost(x_new) -> reduce_step. */
 int sfm_ba_step(sfm_handle h, sfm_ba_problem p, const double* x, double scale, double* x_new);
 int sfm_ba_finish_step(sfm_handle h, sfm_ba_problem p, const double* x, double scale, const double* x_new);
@@ -232,22 +249,23 @@ int sfm_ba_read_scalars(sfm_handle h, sfm_ba_problem p, double* out_host);
 /* ---- the trust-region loop (scipy _lsq/trf.py:401-560 trf_no_bounds + common.py:57-168,222-248,705-717),
  * control flow on the host, every data-parallel stage above on the device.  Same state machine as
  * sfm_amd/trf.py (the host-language mirror the multi-rank CPU tests drive). */
+enum { SFM_SOLVER_DENSE = 0, SFM_SOLVER_PCG = 1 };
 typedef struct {
   double ftol, xtol, gtol;        /* the reference passes ftol = xtol = 1e-4 (:512-513); SciPy's default gtol = 1e-8 */
   int32_t max_nfev;               /* 100 (:511) */
   int32_t max_outer;              /* < 0: no limit; otherwise stop after this many outer iterations (fixed schedules) */
   int32_t check_tolerances;       /* 0 turns the gtol / ftol / xtol tests off (throughput runs) */
+  int32_t solver;                 /* SFM_SOLVER_DENSE: Schur complement + dense Cholesky; SFM_SOLVER_PCG: sfm_ba_solve_pcg */
+  double  pcg_rtol;               /* SFM_SOLVER_PCG: relative residual (<= 0: 1e-13) */
+  int32_t pcg_max_iter;           /* SFM_SOLVER_PCG: iterations per system (<= 0: 4 n, capped at 20000) */
   int32_t reserved;
 } sfm_trf_options;
 typedef struct {
   double cost, optimality;        /* 1/2 sum rho(f^2) and ||g||_inf at the returned x */
   int32_t nfev, njev, status;     /* SciPy's counters and termination status (0: max_nfev, 1 gtol, 2 ftol, 3 xtol, 4 both) */
-  int32_t n_solves, n_outer, reserved;
+  int32_t n_solves, n_outer;
+  int32_t cg_iters;               /* SFM_SOLVER_PCG: conjugate-gradient iterations over all damped solves */
 } sfm_trf_result;
-/* All-reduce `count` doubles at device pointer `data` (inside the bound workspace) in place across the ranks:
- * op 0 = SUM, 1 = MAX.  Return 0 on success.  NULL = single rank. */
-typedef int (*sfm_reduce_fn)(void* user, void* data, int64_t count, int op);
-
 typedef struct sfm_trf_state_s* sfm_trf_state;
 /* x: [n_cams*cam_dim + 3*n_pts] device doubles, start point in, current iterate out (after every sfm_ba_trf_outer).
  * x_norm_pts_only_local: nothing to set - with a reduce hook the point part of ||x|| is summed over the ranks. */

@@ -18,6 +18,7 @@ i32, i64, f64, vp = C.c_int32, C.c_int64, C.c_double, C.c_void_p
 
 
 PREC_FP64, PREC_MIXED = 0, 1
+SOLVER_DENSE, SOLVER_PCG = 0, 1
 
 
 class BADesc(C.Structure):
@@ -39,12 +40,12 @@ class BAStructureView(C.Structure):
 
 class TRFOptions(C.Structure):
     _fields_ = [("ftol", f64), ("xtol", f64), ("gtol", f64), ("max_nfev", i32), ("max_outer", i32),
-                ("check_tolerances", i32), ("reserved", i32)]
+                ("check_tolerances", i32), ("solver", i32), ("pcg_rtol", f64), ("pcg_max_iter", i32), ("reserved", i32)]
 
 
 class TRFResultC(C.Structure):
     _fields_ = [("cost", f64), ("optimality", f64), ("nfev", i32), ("njev", i32), ("status", i32),
-                ("n_solves", i32), ("n_outer", i32), ("reserved", i32)]
+                ("n_solves", i32), ("n_outer", i32), ("cg_iters", i32)]
 
 
 REDUCE_FN = C.CFUNCTYPE(C.c_int, vp, vp, i64, C.c_int)
@@ -55,7 +56,7 @@ class BALayout(C.Structure):
         "total_bytes", "rec_off", "rec_stride", "recB_off", "B_off", "gc_off", "Cp_off", "gp_off",
         "reduce_lin_off", "reduce_lin_count", "gmax_off", "reduce_S_off", "reduce_S_count", "reduce_Sp_off", "reduce_Sp_count",
         "reduce_q_off", "reduce_q_count", "reduce_step_off", "reduce_step_count",
-        "pc_off", "pp_off", "scalars_off", "G_off")]
+        "pc_off", "pp_off", "scalars_off", "G_off", "cg_Ap_off", "cg_M_off")]
 
 
 # name -> (restype, argtypes); every symbol include/sfm_amd.h declares
@@ -82,6 +83,7 @@ SIGNATURES = {
     "sfm_ba_get_layout": (C.c_int, [vp, C.POINTER(BALayout)]),
     "sfm_ba_bind_workspace": (C.c_int, [vp, vp, vp, i64]),
     "sfm_reproj_errors": (C.c_int, [vp, i32, i32, i64, vp, vp, vp, vp, f64, f64, f64, f64, C.c_int, vp]),
+    "sfm_ba_solve_pcg": (C.c_int, [vp, vp, f64, C.c_int, f64, i32, REDUCE_FN, vp, C.POINTER(i32)]),
     "sfm_ba_trf_begin": (C.c_int, [vp, vp, vp, C.POINTER(TRFOptions), REDUCE_FN, vp, C.POINTER(vp)]),
     "sfm_ba_trf_outer": (C.c_int, [vp, C.POINTER(C.c_int)]),
     "sfm_ba_trf_result": (C.c_int, [vp, C.POINTER(TRFResultC)]),

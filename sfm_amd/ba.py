@@ -30,11 +30,14 @@ class GpuBA:
     pts [P,3], observations point-major as the reference packs them (:430-435).  Only these packed
     arrays go in: the index structure of the Schur complement is built on the device by
     sfm_ba_create_problem.  precision="mixed" stores the Jacobian rows in float32 (every sum, W L^-T, S and
-    the solve stay float64).
+    the solve stay float64).  solver="dense" forms the reduced camera system and factors it (default);
+    solver="pcg" solves it by preconditioned conjugate gradients on the implicit Schur complement
+    (sfm_ba_solve_pcg): no n x n matrix, one n-vector exchanged per iteration between ranks.
     """
 
     def __init__(self, cams, pts, cam_idx, pt_idx, uv, K0, width=1024.0, height=768.0,
-                 reg_weight=0.1, device=0, comm=None, precision="fp64"):
+                 reg_weight=0.1, device=0, comm=None, precision="fp64", solver="dense", pcg_rtol=1e-13,
+                 pcg_max_iter=None):
         import torch
         self.torch = torch
         self.comm = comm or LocalComm()
@@ -49,6 +52,10 @@ class GpuBA:
         if precision not in ("fp64", "mixed"):
             raise ValueError(f"unknown precision {precision!r}")
         self.precision = precision
+        if solver not in ("dense", "pcg"):
+            raise ValueError(f"unknown solver {solver!r}")
+        self.solver, self.pcg_rtol, self.pcg_max_iter = solver, float(pcg_rtol), pcg_max_iter
+        self.cg_iters = 0
         ci = np.ascontiguousarray(cam_idx, dtype=np.int32)
         pi = np.ascontiguousarray(pt_idx, dtype=np.int32)
         uvh = np.ascontiguousarray(uv, dtype=np.float64).reshape(-1, 2)
@@ -142,9 +149,19 @@ class GpuBA:
         s = self.scalars()
         return s[_lib.SC_COST], math.sqrt(s[_lib.SC_GNORM2]), s[_lib.SC_GINF], s[_lib.SC_HDIAG]
 
+    def _pcg_max_iter(self):
+        return int(self.pcg_max_iter) if self.pcg_max_iter else min(4 * self.n, 20000)
+
     def solve(self, alpha, want_q):
         L = self.lay
         wq = 1 if want_q else 0
+        if self.solver == "pcg":
+            fn, _keep = self._reduce_hook()
+            its = C.c_int32(0)
+            self.h.call("sfm_ba_solve_pcg", self._pp, C.c_double(alpha), wq, C.c_double(self.pcg_rtol),
+                        self._pcg_max_iter(), fn, None, C.byref(its))
+            self.cg_iters += its.value
+            return self._solve_scalars(alpha)
         self.h.call("sfm_ba_schur_build", self._pp, C.c_double(alpha))
         if self._dist:
             # the factorisation reads only the lower triangle of S: ranks exchange n(n+1)/2 + n doubles, not n^2 + n
@@ -155,6 +172,9 @@ class GpuBA:
         if self._dist:
             self.comm.allreduce_sum(self.view(L.reduce_q_off, L.reduce_q_count))
         self.h.call("sfm_ba_finish_solve", self._pp, wq)
+        return self._solve_scalars(alpha)
+
+    def _solve_scalars(self, alpha):
         s = self.scalars()
         self.n_solves += 1
         fail = s[_lib.SC_CHOL_FAIL]
@@ -246,6 +266,8 @@ class CTrf:
         o.max_nfev = int(min(max_nfev, 2 ** 31 - 1))
         o.max_outer = -1 if max_outer is None else int(max_outer)
         o.check_tolerances = 1 if check_tolerances else 0
+        o.solver = _lib.SOLVER_PCG if be.solver == "pcg" else _lib.SOLVER_DENSE
+        o.pcg_rtol, o.pcg_max_iter = be.pcg_rtol, be._pcg_max_iter()
         self._fn, self._keep = be._reduce_hook()
         self._st = _lib.vp()
         be.h.call("sfm_ba_trf_begin", be._pp, C.c_void_p(be.x.data_ptr()), C.byref(o), self._fn, None, C.byref(self._st))
@@ -265,6 +287,7 @@ class CTrf:
         self.be.h.lib.sfm_ba_trf_trace(self._st, buf, n)
         trace = [(buf[4 * i], buf[4 * i + 1], buf[4 * i + 2], buf[4 * i + 3] != 0.0) for i in range(n)]
         self.be.n_solves = r.n_solves
+        self.be.cg_iters = r.cg_iters
         return TRFResult(r.cost, r.nfev, r.njev, r.status, r.optimality, r.n_solves, trace)
 
     def close(self):

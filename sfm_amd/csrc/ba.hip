@@ -68,6 +68,10 @@ Lay ba_layout(int64_t C, int64_t P, int64_t N, int64_t D, int64_t n_items, int64
   L.sch_part = take(n_items * D * D);
   L.cch_part = take(n_cchunks * 16);
   L.cbl_part = take(n_cchunks * (D * D + D));
+  // implicit-Schur PCG (sfm_ba_solve_pcg): residual, preconditioned residual, direction, S p; block-Jacobi blocks
+  L.cg_r = take(n); L.cg_z = take(n); L.cg_p = take(n); L.cg_Ap = take(n);
+  L.cg_M = take(C * D * D); L.cg_Minv = take(C * D * D);
+  L.cg_scal = take(16);
   L.total = o;
   return L;
 }
@@ -92,6 +96,7 @@ extern "C" int sfm_ba_get_layout(sfm_ba_problem p, sfm_ba_layout* out) {
   out->pc_off = L.pc * 8; out->pp_off = L.pp * 8;
   out->scalars_off = L.scalars * 8;
   out->G_off = L.G * 8;
+  out->cg_Ap_off = L.cg_Ap * 8; out->cg_M_off = L.cg_M * 8;
   return SFM_OK;
 }
 
@@ -1168,6 +1173,326 @@ extern "C" int sfm_ba_finish_solve(sfm_handle h, sfm_ba_problem p, int want_q) {
   hipLaunchKernelGGL(k_finish_solve, dim3(1), dim3(256), 0, h->stream, n, WS(L, pc), WS(L, red_q), WS(L, y),
                      want_q, (const int*)dw.flag, WS(L, scalars));
   SFM_LAUNCH_CHECK(h, "sfm_ba_finish_solve");
+  return SFM_OK;
+}
+
+// ------------------------------------------------------------------------------------ implicit-Schur PCG
+// The damped camera system S y = r,  S = B + alpha I - W (C + alpha I)^-1 W^T, WITHOUT forming or factoring S
+// (SURVEY.md section 7 hard part 4 / 4b): for systems of many cameras (1000 cameras: S is 800 MB and its replicated
+// factorisation 13.8 ms per damped solve) and for the multi-rank split, where the dense route all-reduces n^2/2
+// doubles per solve and factors on every rank while this route exchanges ONE vector of n doubles per iteration.
+//   S v = (B + alpha I) v - sum_{k in camera} G_k u_{pt(k)},   u_j = sum_{k in track j} G_k^T v_{cam(k)}
+// (the same two passes over G the back-substitution makes), preconditioned with the exact diagonal blocks
+// M_c = B_c + alpha I - sum_{k in c} G_k G_k^T (d x d per camera, inverted explicitly).  All CG scalars live on the
+// device (one fused single-workgroup kernel per iteration: alpha, x, r, z = M^-1 r, beta, p); the host only reads
+// ||r||^2 every few iterations.  Vectors of length n are replicated on every rank, sums over observations are
+// rank-local and reduced through the caller's hook - so every rank runs the identical recurrence.
+enum { CG_RZ = 0, CG_RR = 1, CG_RR0 = 2, CG_ITER = 3, CG_FAIL = 4, CG_DOT = 5 };
+
+__global__ __launch_bounds__(256) void k_track_sum(int P, const int* __restrict__ pt_ptr, const double* __restrict__ tmp3,
+                                                   double* __restrict__ u) {
+  const int j = blockIdx.x * 256 + threadIdx.x;
+  if (j >= P) return;
+  double u0 = 0.0, u1 = 0.0, u2 = 0.0;
+  for (int k = pt_ptr[j]; k < pt_ptr[j + 1]; ++k) { u0 += tmp3[(size_t)k * 3]; u1 += tmp3[(size_t)k * 3 + 1]; u2 += tmp3[(size_t)k * 3 + 2]; }
+  u[(size_t)j * 3] = u0; u[(size_t)j * 3 + 1] = u1; u[(size_t)j * 3 + 2] = u2;
+}
+// out[c] = B_c v_c - sum over the camera's chunks of the partial sums of k_cam_reduce_chunks (this rank's part of S v - alpha v)
+template <int D>
+__global__ void k_cam_reduce_final_bv(int C, const int* __restrict__ cch_ptr, const double* __restrict__ part,
+                                      const double* __restrict__ B, const double* __restrict__ v, double* __restrict__ out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= C * D) return;
+  const int c = i / D, a = i - c * D;
+  double t = 0.0;
+  for (int ch = cch_ptr[c]; ch < cch_ptr[c + 1]; ++ch) t += part[(size_t)ch * 16 + a];
+  double bv = 0.0;
+#pragma unroll
+  for (int b = 0; b < D; ++b) bv += B[(size_t)c * D * D + a * D + b] * v[c * D + b];
+  out[i] = bv - t;
+}
+// per chunk of one camera's observations: sum_k G_k G_k^T (D x D), thread (a, b) per entry, fixed order
+template <int D, typename TG, int GS>
+__global__ __launch_bounds__(128) void k_cam_gg_chunks(const int* __restrict__ cch_beg, const int* __restrict__ cch_end,
+                                                       const int* __restrict__ cam_obs, const TG* __restrict__ G,
+                                                       double* __restrict__ part) {
+  const int ch = blockIdx.x, e = threadIdx.x;
+  if (e >= D * D) return;
+  const int a = e / D, b = e - a * D;
+  double acc = 0.0;
+  for (int i = cch_beg[ch]; i < cch_end[ch]; ++i) {
+    const TG* g = G + (size_t)cam_obs[i] * GS;
+    acc += (double)g[a] * (double)g[b] + (double)g[D + a] * (double)g[D + b] + (double)g[2 * D + a] * (double)g[2 * D + b];
+  }
+  part[(size_t)ch * (D * D) + e] = acc;
+}
+template <int D>
+__global__ void k_cam_gg_final(int C, const int* __restrict__ cch_ptr, const double* __restrict__ part,
+                               const double* __restrict__ B, double* __restrict__ M) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= C * D * D) return;
+  const int c = i / (D * D), e = i - c * D * D;
+  double t = 0.0;
+  for (int ch = cch_ptr[c]; ch < cch_ptr[c + 1]; ++ch) t += part[(size_t)ch * (D * D) + e];
+  M[i] = B[i] - t;
+}
+// Minv_c = (M_c + alpha I)^-1 by Cholesky, one thread per camera (D <= 10: 100 doubles of registers / scratch)
+template <int D>
+__global__ void k_precond_invert(int C, const double* __restrict__ M, double alpha, double* __restrict__ Minv,
+                                 double* __restrict__ scal) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  double L[D][D], X[D][D];
+#pragma unroll
+  for (int i = 0; i < D; ++i)
+#pragma unroll
+    for (int j = 0; j < D; ++j) L[i][j] = 0.5 * (M[(size_t)c * D * D + i * D + j] + M[(size_t)c * D * D + j * D + i]) + (i == j ? alpha : 0.0);
+  bool bad = false;
+#pragma unroll
+  for (int j = 0; j < D; ++j) {
+    double s = L[j][j];
+#pragma unroll
+    for (int k = 0; k < j; ++k) s -= L[j][k] * L[j][k];
+    if (!(s > 0.0)) { bad = true; s = 1.0; }
+    const double l = sqrt(s);
+    L[j][j] = l;
+#pragma unroll
+    for (int i = j + 1; i < D; ++i) {
+      double t = L[i][j];
+#pragma unroll
+      for (int k = 0; k < j; ++k) t -= L[i][k] * L[j][k];
+      L[i][j] = t / l;
+    }
+  }
+  // X = L^-1 (lower), then Minv = X^T X
+#pragma unroll
+  for (int t = 0; t < D; ++t)
+#pragma unroll
+    for (int r = 0; r < D; ++r) {
+      double sum = (r == t) ? 1.0 : 0.0;
+#pragma unroll
+      for (int k = 0; k < r; ++k) sum -= (k >= t ? L[r][k] * X[k][t] : 0.0);
+      X[r][t] = (r >= t) ? sum / L[r][r] : 0.0;
+    }
+#pragma unroll
+  for (int i = 0; i < D; ++i)
+#pragma unroll
+    for (int j = 0; j < D; ++j) {
+      double sum = 0.0;
+#pragma unroll
+      for (int k = 0; k < D; ++k) sum += X[k][i] * X[k][j];
+      Minv[(size_t)c * D * D + i * D + j] = sum;
+    }
+  if (bad) scal[CG_FAIL] = 1.0;
+}
+
+// Sum over a 1024-thread block, fixed order; every thread gets the result.  s: >= 17 doubles of LDS.
+__device__ __forceinline__ double block_sum1024(double v, double* s) {
+  v = wave_sum(v);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) s[threadIdx.x >> 6] = v;
+  __syncthreads();
+  double t = 0.0;
+#pragma unroll
+  for (int w = 0; w < 16; ++w) t += s[w];
+  return t;
+}
+// z = Minv r per camera block (thread i owns row i of its block)
+template <int D>
+__device__ __forceinline__ double precond_row(const double* __restrict__ Minv, const double* __restrict__ r, int i) {
+  const int c = i / D, a = i - c * D;
+  const double* m = Minv + (size_t)c * D * D + a * D;
+  double z = 0.0;
+#pragma unroll
+  for (int b = 0; b < D; ++b) z += m[b] * r[c * D + b];
+  return z;
+}
+// start: x = 0, r = rhs, z = M^-1 r, p = z; scalars rz, rr, rr0
+template <int D>
+__global__ __launch_bounds__(1024) void k_cg_init(int n, const double* __restrict__ rhs, const double* __restrict__ Minv,
+                                                  double* __restrict__ x, double* __restrict__ r, double* __restrict__ z,
+                                                  double* __restrict__ pv, double* __restrict__ scal) {
+  __shared__ double s_red[17];
+  double rz = 0.0, rr = 0.0;
+  for (int i = threadIdx.x; i < n; i += 1024) { x[i] = 0.0; r[i] = rhs[i]; }
+  __syncthreads();
+  for (int i = threadIdx.x; i < n; i += 1024) {
+    const double zi = precond_row<D>(Minv, rhs, i);
+    z[i] = zi; pv[i] = zi;
+    rz += rhs[i] * zi; rr += rhs[i] * rhs[i];
+  }
+  rz = block_sum1024(rz, s_red);
+  rr = block_sum1024(rr, s_red);
+  if (threadIdx.x == 0) { scal[CG_RZ] = rz; scal[CG_RR] = rr; scal[CG_RR0] = rr; scal[CG_ITER] = 0.0; }
+}
+// one CG iteration after the product: Ap = (reduced B p - W C^-1 W^T p) + alpha p
+template <int D>
+__global__ __launch_bounds__(1024) void k_cg_step(int n, double alpha, double* __restrict__ Ap, double* __restrict__ pv,
+                                                  double* __restrict__ x, double* __restrict__ r, double* __restrict__ z,
+                                                  const double* __restrict__ Minv, double* __restrict__ scal) {
+  __shared__ double s_red[17];
+  const double rz = scal[CG_RZ];
+  double pAp = 0.0;
+  for (int i = threadIdx.x; i < n; i += 1024) { const double ap = Ap[i] + alpha * pv[i]; Ap[i] = ap; pAp += pv[i] * ap; }
+  pAp = block_sum1024(pAp, s_red);
+  if (!(pAp > 0.0) || rz == 0.0) {            // S is not positive definite (or the residual vanished exactly): stop moving
+    if (threadIdx.x == 0) { if (!(pAp > 0.0) && rz != 0.0) scal[CG_FAIL] = 2.0; scal[CG_RR] = (rz == 0.0) ? 0.0 : scal[CG_RR]; }
+    return;
+  }
+  const double a = rz / pAp;
+  for (int i = threadIdx.x; i < n; i += 1024) { x[i] += a * pv[i]; r[i] -= a * Ap[i]; }
+  __syncthreads();                              // r complete before the block-wise preconditioner reads it
+  double rz_new = 0.0, rr = 0.0;
+  for (int i = threadIdx.x; i < n; i += 1024) {
+    const double zi = precond_row<D>(Minv, r, i);
+    z[i] = zi;
+    rz_new += r[i] * zi; rr += r[i] * r[i];
+  }
+  rz_new = block_sum1024(rz_new, s_red);
+  rr = block_sum1024(rr, s_red);
+  const double beta = rz_new / rz;
+  for (int i = threadIdx.x; i < n; i += 1024) pv[i] = z[i] + beta * pv[i];
+  if (threadIdx.x == 0) { scal[CG_RZ] = rz_new; scal[CG_RR] = rr; scal[CG_ITER] += 1.0; }
+}
+__global__ __launch_bounds__(1024) void k_dot(int n, const double* __restrict__ a, const double* __restrict__ b, double* __restrict__ out) {
+  __shared__ double s_red[17];
+  double t = 0.0;
+  for (int i = threadIdx.x; i < n; i += 1024) t += a[i] * b[i];
+  t = block_sum1024(t, s_red);
+  if (threadIdx.x == 0) *out = t;
+}
+// scalars after a PCG solve: PNORM2 = ||p_c||^2 + sum ||p_p||^2, PQ = rhs2^T S^-1 rhs2 + sum ||v||^2, failure code
+__global__ __launch_bounds__(256) void k_finish_solve_pcg(int n, const double* __restrict__ pc, const double* __restrict__ red_q,
+                                                          int want_q, const double* __restrict__ cg_scal, double* __restrict__ sc) {
+  __shared__ double s_red[4];
+  double a = 0.0;
+  for (int i = threadIdx.x; i < n; i += 256) a += pc[i] * pc[i];
+  const double at = block_sum256(a, s_red);
+  if (threadIdx.x == 0) {
+    const double pn2 = at + red_q[n], pq = want_q ? (cg_scal[CG_DOT] + red_q[n + 1]) : 0.0;
+    sc[SFM_SC_PNORM2] = pn2; sc[SFM_SC_PQ] = pq;
+    double f = cg_scal[CG_FAIL] != 0.0 ? 1.0 : 0.0;        // 1: a block or S itself is not positive definite
+    if (f == 0.0 && !(isfinite(pn2) && isfinite(pq))) f = 3.0;
+    sc[SFM_SC_CHOL_FAIL] = f;
+  }
+}
+
+namespace {
+struct Pcg {
+  sfm_ctx* h; sfm_ba_problem p; Lay L; double* ws; double alpha, rtol; int max_iter;
+  sfm_reduce_fn reduce; void* user;
+  int iters;
+
+  int red(double* ptr, int64_t count) {
+    if (!reduce) return SFM_OK;
+    return reduce(user, ptr, count, 0) ? sfm_fail(h, SFM_ERR_HIP, "sfm_ba_solve_pcg", "the reduce hook failed") : SFM_OK;
+  }
+  // this rank's part of (S - alpha I) v -> cg_Ap, reduced over the ranks
+  int matvec(const double* v) {
+    const int C = p->n_cams, P = p->n_pts, D = p->cam_dim, n = C * D;
+    const int64_t N = p->n_obs;
+    DISPATCH_DT(D, p->precision, {
+      hipLaunchKernelGGL((k_obs_Gtp<DD, double, GG>), dim3(cdiv(N * 3, 256)), dim3(256), 0, h->stream, N * 3, p->cam_idx, WS(L, G), v, WS(L, tmp3));
+      hipLaunchKernelGGL(k_track_sum, dim3(cdiv(P, 256)), dim3(256), 0, h->stream, P, p->pt_ptr, WS(L, tmp3), WS(L, v));
+      if (p->n_cchunks > 0)
+        hipLaunchKernelGGL((k_cam_reduce_chunks<DD, double, GG>), dim3((unsigned)p->n_cchunks), dim3(256), 0, h->stream, p->cch_beg,
+                           p->cch_end, p->cam_obs, p->pt_idx, WS(L, G), WS(L, v), WS(L, cch_part));
+      hipLaunchKernelGGL(k_cam_reduce_final_bv<DD>, dim3(cdiv(n, 256)), dim3(256), 0, h->stream, C, p->cch_ptr, WS(L, cch_part), WS(L, B),
+                         v, WS(L, cg_Ap));
+    });
+    return red(WS(L, cg_Ap), n);
+  }
+  // x = S^-1 rhs (x, rhs: device vectors of n doubles, distinct from the cg_* work vectors)
+  int solve(const double* rhs, double* x) {
+    const int D = p->cam_dim, n = p->n_cams * D;
+    DISPATCH_D(D, hipLaunchKernelGGL(k_cg_init<DD>, dim3(1), dim3(1024), 0, h->stream, n, rhs, WS(L, cg_Minv), x, WS(L, cg_r), WS(L, cg_z),
+                                     WS(L, cg_p), WS(L, cg_scal)));
+    const int check_every = 8;
+    for (int it = 0; it < max_iter; ++it) {
+      int rc = matvec(WS(L, cg_p)); if (rc) return rc;
+      DISPATCH_D(D, hipLaunchKernelGGL(k_cg_step<DD>, dim3(1), dim3(1024), 0, h->stream, n, alpha, WS(L, cg_Ap), WS(L, cg_p), x, WS(L, cg_r),
+                                       WS(L, cg_z), WS(L, cg_Minv), WS(L, cg_scal)));
+      ++iters;
+      if ((it + 1) % check_every == 0 || it + 1 == max_iter) {
+        SFM_HIP(h, hipMemcpyAsync(h->pinned, WS(L, cg_scal), 8 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+        SFM_HIP(h, hipStreamSynchronize(h->stream));
+        const double rr = h->pinned[CG_RR], rr0 = h->pinned[CG_RR0];
+        if (h->pinned[CG_FAIL] != 0.0 || !(rr == rr)) break;               // reported through the scalars
+        if (rr <= rtol * rtol * rr0) break;
+      }
+    }
+    SFM_LAUNCH_CHECK(h, "sfm_ba_solve_pcg");
+    return SFM_OK;
+  }
+};
+}  // namespace
+
+extern "C" int sfm_ba_solve_pcg(sfm_handle h, sfm_ba_problem p, double alpha, int want_q, double rtol, int32_t max_iter,
+                                sfm_reduce_fn reduce, void* reduce_user, int32_t* iters_host) {
+  Lay L; int rc = check_problem(h, p, &L); if (rc) return rc;
+  if (!(alpha > 0.0) || !(rtol > 0.0) || max_iter < 1) return sfm_fail(h, SFM_ERR_ARG, "sfm_ba_solve_pcg", "alpha, rtol > 0 and max_iter >= 1");
+  double* ws = (double*)p->workspace;
+  const int C = p->n_cams, P = p->n_pts, D = p->cam_dim, n = C * D;
+  const int64_t N = p->n_obs;
+  Pcg cg{h, p, L, ws, alpha, rtol, max_iter, reduce, reduce_user, 0};
+  SFM_HIP(h, hipMemsetAsync(WS(L, cg_scal), 0, 16 * sizeof(double), h->stream));
+  // point factors, G, and this rank's part of the right-hand side r = g_c - W C_a^-1 g_p and of the diagonal blocks
+  sfm_prof_begin(h, SFM_PROF_BUILD_G);
+  hipLaunchKernelGGL(k_point_factor, dim3(cdiv(P, 256)), dim3(256), 0, h->stream, P, alpha, WS(L, Cp), WS(L, gp), WS(L, Linv), WS(L, e));
+  DISPATCH_DT(D, p->precision, {
+    hipLaunchKernelGGL((k_build_G<DD, TT, double, GG>), dim3(cdiv(N * 16, 256)), dim3(256), 0, h->stream, N, p->pt_idx, WST(L, recA),
+                       WST(L, recB), WS(L, Linv), WS(L, G));
+    sfm_prof_end(h, SFM_PROF_BUILD_G);
+    sfm_prof_begin(h, SFM_PROF_SCHUR);
+    if (p->n_cchunks > 0) {
+      hipLaunchKernelGGL((k_cam_reduce_chunks<DD, double, GG>), dim3((unsigned)p->n_cchunks), dim3(256), 0, h->stream, p->cch_beg,
+                         p->cch_end, p->cam_obs, p->pt_idx, WS(L, G), WS(L, e), WS(L, cch_part));
+      hipLaunchKernelGGL((k_cam_gg_chunks<DD, double, GG>), dim3((unsigned)p->n_cchunks), dim3(128), 0, h->stream, p->cch_beg, p->cch_end,
+                         p->cam_obs, WS(L, G), WS(L, cbl_part));
+    }
+    hipLaunchKernelGGL(k_cam_reduce_final<DD>, dim3(cdiv(n, 256)), dim3(256), 0, h->stream, C, p->cch_ptr, WS(L, cch_part), WS(L, gc),
+                       WS(L, tvec));
+    hipLaunchKernelGGL(k_cam_gg_final<DD>, dim3(cdiv((int64_t)n * DD, 256)), dim3(256), 0, h->stream, C, p->cch_ptr, WS(L, cbl_part),
+                       WS(L, B), WS(L, cg_M));
+    sfm_prof_end(h, SFM_PROF_SCHUR);
+  });
+  if ((rc = cg.red(WS(L, tvec), n))) return rc;
+  if ((rc = cg.red(WS(L, cg_M), (int64_t)n * D))) return rc;
+  sfm_prof_begin(h, SFM_PROF_CHOL);            // the slot of the camera solve: here the CG iterations
+  DISPATCH_D(D, hipLaunchKernelGGL(k_precond_invert<DD>, dim3(cdiv(C, 64)), dim3(64), 0, h->stream, C, WS(L, cg_M), alpha, WS(L, cg_Minv),
+                                   WS(L, cg_scal)));
+  // y = S^-1 r ; p_c = -y
+  if ((rc = cg.solve(WS(L, tvec), WS(L, y)))) return rc;
+  hipLaunchKernelGGL(k_copy_neg, dim3(cdiv(n, 256)), dim3(256), 0, h->stream, WS(L, y), WS(L, pc), n, -1.0);
+  sfm_prof_end(h, SFM_PROF_CHOL);
+  sfm_prof_begin(h, SFM_PROF_BACKSUB);
+  DISPATCH_DT(D, p->precision, hipLaunchKernelGGL((k_obs_Gtp<DD, double, GG>), dim3(cdiv(N * 3, 256)), dim3(256), 0, h->stream, N * 3,
+                                                  p->cam_idx, WS(L, G), WS(L, pc), WS(L, tmp3)));
+  hipLaunchKernelGGL(k_backsub, dim3((unsigned)L.nblk_pt), dim3(256), 0, h->stream, P, p->pt_ptr, WS(L, tmp3), WS(L, Linv), WS(L, e),
+                     WS(L, pp), WS(L, v), WS(L, part_pt));
+  hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(256), 0, h->stream, WS(L, part_pt), (int)L.nblk_pt, 2, WS(L, red_q) + n);
+  if (want_q) {
+    DISPATCH_DT(D, p->precision, {
+      if (p->n_cchunks > 0)
+        hipLaunchKernelGGL((k_cam_reduce_chunks<DD, double, GG>), dim3((unsigned)p->n_cchunks), dim3(256), 0, h->stream, p->cch_beg,
+                           p->cch_end, p->cam_obs, p->pt_idx, WS(L, G), WS(L, v), WS(L, cch_part));
+      hipLaunchKernelGGL(k_cam_reduce_final<DD>, dim3(cdiv(n, 256)), dim3(256), 0, h->stream, C, p->cch_ptr, WS(L, cch_part),
+                         (const double*)nullptr, WS(L, red_q));
+    });
+  }
+  sfm_prof_end(h, SFM_PROF_BACKSUB);
+  if ((rc = cg.red(WS(L, red_q), n + 2))) return rc;
+  if (want_q) {
+    // rhs2 = p_c - W C_a^-1 p_p ;  p^T (H + alpha I)^-1 p = rhs2^T S^-1 rhs2 + sum ||v||^2
+    sfm_prof_begin(h, SFM_PROF_TRSV);
+    hipLaunchKernelGGL(k_add_vec, dim3(cdiv(n, 256)), dim3(256), 0, h->stream, WS(L, pc), WS(L, red_q), WS(L, tvec), n);
+    if ((rc = cg.solve(WS(L, tvec), WS(L, y)))) return rc;
+    hipLaunchKernelGGL(k_dot, dim3(1), dim3(1024), 0, h->stream, n, WS(L, tvec), WS(L, y), WS(L, cg_scal) + CG_DOT);
+    sfm_prof_end(h, SFM_PROF_TRSV);
+  }
+  hipLaunchKernelGGL(k_finish_solve_pcg, dim3(1), dim3(256), 0, h->stream, n, WS(L, pc), WS(L, red_q), want_q, WS(L, cg_scal), WS(L, scalars));
+  SFM_LAUNCH_CHECK(h, "sfm_ba_solve_pcg");
+  if (iters_host) *iters_host = cg.iters;
   return SFM_OK;
 }
 

@@ -26,6 +26,7 @@ struct sfm_trf_state_s {
   sfm_ba_layout lay;
   double cost, g_norm, g_inf, hdiag, x_norm, Delta, alpha;
   int nfev, njev, status /* -1: running */, iteration, n_solves;
+  long long cg_iters;
   std::vector<double> trace;
 };
 
@@ -55,6 +56,15 @@ struct Backend {
   }
   int solve(double alpha, int want_q, double* p_norm, double* pq) {
     int rc;
+    if (s->opt.solver == SFM_SOLVER_PCG) {
+      const int n = s->p->n_cams * s->p->cam_dim;
+      const double rtol = s->opt.pcg_rtol > 0 ? s->opt.pcg_rtol : 1e-13;
+      const int mit = s->opt.pcg_max_iter > 0 ? s->opt.pcg_max_iter : (4 * n < 20000 ? 4 * n : 20000);
+      int32_t its = 0;
+      if ((rc = sfm_ba_solve_pcg(s->h, s->p, alpha, want_q, rtol, mit, s->reduce, s->reduce_user, &its))) return rc;
+      s->cg_iters += its;
+      return after_solve(p_norm, pq);
+    }
     if ((rc = sfm_ba_schur_build(s->h, s->p, alpha))) return rc;
     if (s->reduce) {
       if ((rc = sfm_ba_pack_system(s->h, s->p))) return rc;
@@ -64,6 +74,10 @@ struct Backend {
     if ((rc = sfm_ba_schur_solve(s->h, s->p, alpha, want_q))) return rc;
     if ((rc = red(s->lay.reduce_q_off, s->lay.reduce_q_count, 0))) return rc;
     if ((rc = sfm_ba_finish_solve(s->h, s->p, want_q))) return rc;
+    return after_solve(p_norm, pq);
+  }
+  int after_solve(double* p_norm, double* pq) {
+    int rc;
     if ((rc = scalars())) return rc;
     s->n_solves++;
     if (sc[SFM_SC_CHOL_FAIL] != 0.0)
@@ -156,6 +170,7 @@ extern "C" int sfm_ba_trf_begin(sfm_handle h, sfm_ba_problem p, double* x, const
   if (!p->workspace) return sfm_fail(h, SFM_ERR_WORKSPACE, "sfm_ba_trf_begin", "no workspace bound (sfm_ba_bind_workspace)");
   sfm_trf_state_s* s = new sfm_trf_state_s();
   s->h = h; s->p = p; s->x = x; s->x_new = nullptr; s->opt = *opt; s->reduce = reduce; s->reduce_user = reduce_user;
+  s->cg_iters = 0;
   sfm_ba_get_layout(p, &s->lay);
   const size_t bytes = ((size_t)p->n_cams * p->cam_dim + 3 * (size_t)p->n_pts) * sizeof(double);
   if (hipMalloc((void**)&s->x_new, bytes) != hipSuccess) { delete s; return sfm_fail(h, SFM_ERR_HIP, "sfm_ba_trf_begin", "hipMalloc"); }
@@ -219,7 +234,7 @@ extern "C" int sfm_ba_trf_result(sfm_trf_state s, sfm_trf_result* out) {
   if (!s || !out) return SFM_ERR_ARG;
   out->cost = s->cost; out->optimality = s->g_inf;
   out->nfev = s->nfev; out->njev = s->njev; out->status = s->status < 0 ? 0 : s->status;
-  out->n_solves = s->n_solves; out->n_outer = s->iteration; out->reserved = 0;
+  out->n_solves = s->n_solves; out->n_outer = s->iteration; out->cg_iters = (int32_t)(s->cg_iters > 0x7fffffff ? 0x7fffffff : s->cg_iters);
   return SFM_OK;
 }
 
