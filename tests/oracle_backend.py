@@ -14,7 +14,9 @@ from sfm_amd.structure import build_structure
 
 
 class OracleBackend:
-    def __init__(self, prob, x0, comm=None):
+    def __init__(self, prob, x0, comm=None, solver="dense"):
+        self.solver = solver          # "pcg": the algebra of sfm_ba_solve_pcg (implicit Schur complement, block-Jacobi CG)
+        self.cg_iters = 0
         self.prob = prob
         self.comm = comm or LocalComm()
         self.x = np.asarray(x0, dtype=np.float64).copy()
@@ -57,6 +59,8 @@ class OracleBackend:
         G = np.einsum("nij,nkj->nik", W, M[pr.pt_idx])               # W L^-T   [N,d,3]
         g_p = lin.g[n:].reshape(-1, 3)
         e = np.einsum("pij,pj->pi", M, g_p)
+        if self.solver == "pcg":
+            return self._solve_pcg(alpha, want_q, G, M, e)
         S = np.zeros((n, n))
         for c in range(pr.n_cams):
             S[c * d:(c + 1) * d, c * d:(c + 1) * d] = lin.B[c]
@@ -93,6 +97,62 @@ class OracleBackend:
         if want_q:
             yy = np.linalg.solve(Ls, pc + red[:n])
             pq = float(yy @ yy) + red[n + 1]
+        return math.sqrt(pnorm2), pq
+
+    def _solve_pcg(self, alpha, want_q, G, M, e):
+        """Same staged algebra as sfm_ba_solve_pcg: per call one reduction of the right-hand side and of the diagonal
+        blocks, per CG iteration one reduction of an n-vector; every rank runs the identical recurrence."""
+        pr, lin, n, d = self.prob, self.lin, self.n, self.prob.d
+        C = pr.n_cams
+
+        def local_matvec(v):          # this rank's part of (S - alpha I) v
+            vc = v.reshape(C, d)
+            t = np.einsum("nij,ni->nj", G, vc[pr.cam_idx])                    # G_k^T v_cam(k)
+            u = np.zeros((pr.n_pts, 3)); np.add.at(u, pr.pt_idx, t)           # per track
+            out = np.einsum("cij,cj->ci", lin.B, vc)
+            np.add.at(out, pr.cam_idx, -np.einsum("nij,nj->ni", G, u[pr.pt_idx]))
+            return out.ravel()
+
+        r = lin.g[:n].reshape(C, d).copy()
+        np.add.at(r, pr.cam_idx, -np.einsum("nij,nj->ni", G, e[pr.pt_idx]))
+        blocks = lin.B.copy()
+        np.add.at(blocks, pr.cam_idx, -np.einsum("nim,njm->nij", G, G))
+        red = self._sum(np.concatenate([r.ravel(), blocks.ravel()]))
+        r, blocks = red[:n], red[n:].reshape(C, d, d) + alpha * np.eye(d)[None]
+        Minv = np.linalg.inv(blocks)
+
+        def cg(rhs):
+            x = np.zeros(n); res = rhs.copy()
+            z = np.einsum("cij,cj->ci", Minv, res.reshape(C, d)).ravel(); pv = z.copy()
+            rz, rr0 = float(res @ z), float(res @ res)
+            for _ in range(20 * n):
+                Ap = self._sum(local_matvec(pv)) + alpha * pv
+                a = rz / float(pv @ Ap)
+                x += a * pv; res -= a * Ap
+                self.cg_iters += 1
+                if float(res @ res) <= 1e-26 * rr0:
+                    break
+                z = np.einsum("cij,cj->ci", Minv, res.reshape(C, d)).ravel()
+                rz_new = float(res @ z)
+                pv = z + (rz_new / rz) * pv
+                rz = rz_new
+            return x
+
+        pc = -cg(r)
+        u = e.copy()
+        np.add.at(u, pr.pt_idx, np.einsum("nij,ni->nj", G, pc.reshape(-1, d)[pr.cam_idx]))
+        pp = -np.einsum("pji,pj->pi", M, u)
+        v = np.einsum("pij,pj->pi", M, pp)
+        rhs2 = np.zeros((C, d))
+        np.add.at(rhs2, pr.cam_idx, -np.einsum("nij,nj->ni", G, v[pr.pt_idx]))
+        red = self._sum(np.concatenate([rhs2.ravel(), [np.sum(pp ** 2), np.sum(v ** 2)]]))
+        self.pc, self.pp = pc, pp.ravel()
+        self.n_solves += 1
+        pnorm2 = float(pc @ pc) + red[n]
+        pq = 0.0
+        if want_q:
+            b2 = pc + red[:n]
+            pq = float(b2 @ cg(b2)) + red[n + 1]
         return math.sqrt(pnorm2), pq
 
     def step(self, scale):

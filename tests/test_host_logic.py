@@ -75,12 +75,13 @@ def test_reference_order_is_a_permutation_of_uv():
 
 
 # ------------------------------------------------------------------ host TRF loop + structures (oracle-backed)
+@pytest.mark.parametrize("solver", ["dense", "pcg"])
 @pytest.mark.parametrize("name", ["ba_c5p50_n05_aligned.npz", "ba_c8p60_L4_reference.npz", "ba_c6p40_cam_reference.npz"])
-def test_host_trf_loop_with_oracle_backend(name):
+def test_host_trf_loop_with_oracle_backend(name, solver):
     from oracle_backend import OracleBackend
     from sfm_amd.trf import trf
     g, prob, x0 = load_golden_problem(name)
-    be = OracleBackend(prob, x0)
+    be = OracleBackend(prob, x0, solver=solver)
     res = trf(be)
     assert (res.nfev, res.njev, res.status) == (int(g["nfev"]), int(g["njev"]), int(g["status"]))
     assert np.max(np.abs(be.x - g["x"]) / np.maximum(np.abs(g["x"]), 1e-3)) <= 2e-5
@@ -128,7 +129,7 @@ st = build_structure(prob.cam_idx, prob.pt_idx, C, prob.n_pts)
 lo, hi = partition_points(st.pt_ptr, 2)[comm.rank]
 ci, pi, uv, pts = shard_arrays(prob.cam_idx, prob.pt_idx, prob.uv, x0[C * d:].reshape(-1, 3), lo, hi)
 local = bo.BAProblem(C, hi - lo, d, ci, pi, uv, prob.K0, reg_weight=(prob.reg_weight if comm.rank == 0 else 0.0))
-be = OracleBackend(local, np.concatenate([x0[:C * d], pts.ravel()]), comm)
+be = OracleBackend(local, np.concatenate([x0[:C * d], pts.ravel()]), comm, solver={solver!r})
 res = trf(be)
 parts = comm.all_gather_objects((lo, hi, be.x[C * d:]))
 if comm.rank == 0:
@@ -139,14 +140,16 @@ dist.destroy_process_group()
 '''
 
 
-@pytest.mark.parametrize("name", ["ba_c8p60_L4_aligned.npz", "ba_c10p100_n05_reference.npz"])
-def test_two_rank_sharded_solve_over_gloo(name, tmp_path):
-    """Points sharded over 2 ranks, cameras replicated, [S | r] and the short vectors all-reduced over
-    gloo: same iteration counts and parameters as the reference's single-process run."""
+@pytest.mark.parametrize("name,solver", [("ba_c8p60_L4_aligned.npz", "dense"), ("ba_c10p100_n05_reference.npz", "dense"),
+                                         ("ba_c8p60_L4_aligned.npz", "pcg"), ("ba_c6p40_cam_reference.npz", "pcg")])
+def test_two_rank_sharded_solve_over_gloo(name, solver, tmp_path):
+    """Points sharded over 2 ranks, cameras replicated, [S | r] (dense route) or one n-vector per CG iteration
+    (implicit-Schur PCG route) and the short vectors all-reduced over gloo: same iteration counts and parameters as
+    the reference's single-process run."""
     g, _, _ = load_golden_problem(name)
     port = 29500 + (os.getpid() % 2000)
     script = tmp_path / "worker.py"
-    script.write_text(_WORKER.format(root=ROOT, port=port, name=name))
+    script.write_text(_WORKER.format(root=ROOT, port=port, name=name, solver=solver))
     procs = [subprocess.Popen([sys.executable, str(script), str(r)], stdout=subprocess.PIPE, stderr=subprocess.PIPE,
                               text=True) for r in range(2)]
     outs = [p.communicate(timeout=240) for p in procs]
