@@ -46,6 +46,9 @@ def parse():
     ap.add_argument("--no-mixed", action="store_true")
     ap.add_argument("--no-dropin", action="store_true")
     ap.add_argument("--no-pcg", action="store_true")
+    ap.add_argument("--camera-solver", default="auto", choices=("auto", "cholesky", "cg"),
+                    help="how the formed camera system is solved in the headline run")
+    ap.add_argument("--no-alt-camera-solver", action="store_true")
     ap.add_argument("--no-driver-rows", action="store_true")
     return ap.parse_args()
 
@@ -108,10 +111,10 @@ def main():
     n_obs_total = sc.n_obs
     n_sys = C * d
 
-    def fixed_schedule_run(cam_dim, precision, profile, solver="dense"):
+    def fixed_schedule_run(cam_dim, precision, profile, solver="dense", camera_solver=None):
         """W warm-up + K timed outer iterations of the trust-region loop (library side, termination tests off)."""
         be = GpuBA(sc.cams0[:, :cam_dim], pts0, ci, pi, uv, synth.K_REF, device=local_rank, comm=comm, precision=precision,
-                   solver=solver)
+                   solver=solver, camera_solver=camera_solver or args.camera_solver)
         st = be.trf_begin(max_nfev=2 ** 31 - 1, check_tolerances=False)
         cost0 = st.result().cost
         for _ in range(args.warmup):
@@ -132,8 +135,9 @@ def main():
             be.h.set_profiling(False)
         r1 = st.result()
         cg_iters = be.cg_iters
+        cam_cg = be.solver_stats()
         st.close()
-        out = {"cg_iters": cg_iters, "elapsed": elapsed, "value": args.steps / elapsed, "ms_per_step": elapsed / args.steps * 1e3,
+        out = {"cg_iters": cg_iters, "camera_cg": cam_cg, "elapsed": elapsed, "value": args.steps / elapsed, "ms_per_step": elapsed / args.steps * 1e3,
                "damped_solves": r1.n_solves - r0.n_solves, "trial_steps": r1.nfev - r0.nfev, "cost_start": cost0,
                "cost_end": r1.cost, "n_pairs": be.n_pairs, "n_obs_local": be.N, "prof": prof}
         del st, be
@@ -212,6 +216,14 @@ def main():
                              "solve in float64 (opt-in; the headline stays float64)")
         ba_mixed["kernels_us"] = {k: round(v[0] / v[1] * 1e3, 2) for k, v in rm["prof"].items() if v[1] > 0}
 
+    ba_alt = None
+    if not args.no_alt_camera_solver and n_sys <= 4096:
+        other = "cg" if args.camera_solver == "cholesky" else "cholesky"       # auto = cg at this size
+        ra = fixed_schedule_run(d, "fp64", True, camera_solver=other)
+        ba_alt = brief(ra, f"same scene and schedule, formed camera system solved by {other} instead of {args.camera_solver}")
+        ba_alt["camera_solver"] = other
+        ba_alt["cg_iterations_and_fallbacks_incl_warmup"] = ra["camera_cg"]
+        ba_alt["kernels_us"] = {k: round(v[0] / v[1] * 1e3, 2) for k, v in ra["prof"].items() if v[1] > 0}
     ba_pcg = None
     if not args.no_pcg:
         rp = fixed_schedule_run(d, "fp64", True, solver="pcg")
@@ -359,8 +371,10 @@ def main():
             "ba": {"damped_solves": main["damped_solves"], "trial_steps": main["trial_steps"], "cost_start": main["cost_start"],
                    "cost_end": main["cost_end"], "solves_per_s": main["damped_solves"] / elapsed, "kernels": kernels,
                    "kernels_note": "HIP-event times from a second pass of the same schedule; the timed pass carries no events",
-                   "loop": "sfm_ba_trf_outer (library-side trust-region loop)"},
-            "ba_cam_dim6": ba_d6, "ba_mixed_precision": ba_mixed, "ba_pcg_solver": ba_pcg, "dropin": dropin,
+                   "loop": "sfm_ba_trf_outer (library-side trust-region loop)", "camera_solver": args.camera_solver,
+                   "camera_cg_iterations_and_fallbacks_incl_warmup": main["camera_cg"]},
+            "ba_cam_dim6": ba_d6, "ba_mixed_precision": ba_mixed, "ba_other_camera_solver": ba_alt, "ba_pcg_solver": ba_pcg,
+            "dropin": dropin,
             "roofline": roofline, "rooflines": roofs, "cpu_baseline": cpu_baseline, "matcher": matcher,
             "driver_rows": driver_rows,
         }

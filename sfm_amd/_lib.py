@@ -19,6 +19,7 @@ i32, i64, f64, vp = C.c_int32, C.c_int64, C.c_double, C.c_void_p
 
 PREC_FP64, PREC_MIXED = 0, 1
 SOLVER_DENSE, SOLVER_PCG = 0, 1
+CAMERA_AUTO, CAMERA_CHOLESKY, CAMERA_CG = 0, 1, 2
 
 
 class BADesc(C.Structure):
@@ -28,7 +29,7 @@ class BADesc(C.Structure):
                 ("cam_idx", vp), ("pt_idx", vp), ("uv", vp),
                 ("fx0", f64), ("fy0", f64), ("cx0", f64), ("cy0", f64),
                 ("width", f64), ("height", f64), ("reg_weight", f64),
-                ("precision", i32), ("reserved", i32)]
+                ("precision", i32), ("camera_solver", i32)]
 
 
 class BAStructureView(C.Structure):
@@ -81,6 +82,7 @@ SIGNATURES = {
     "sfm_ba_destroy_problem": (None, [vp]),
     "sfm_ba_get_structure": (C.c_int, [vp, C.POINTER(BAStructureView)]),
     "sfm_ba_get_layout": (C.c_int, [vp, C.POINTER(BALayout)]),
+    "sfm_ba_solver_stats": (C.c_int, [vp, C.POINTER(i64), C.POINTER(i64)]),
     "sfm_ba_bind_workspace": (C.c_int, [vp, vp, vp, i64]),
     "sfm_reproj_errors": (C.c_int, [vp, i32, i32, i64, vp, vp, vp, vp, f64, f64, f64, f64, C.c_int, vp]),
     "sfm_ba_solve_pcg": (C.c_int, [vp, vp, f64, C.c_int, f64, i32, REDUCE_FN, vp, C.POINTER(i32)]),

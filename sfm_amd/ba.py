@@ -33,11 +33,14 @@ class GpuBA:
     the solve stay float64).  solver="dense" forms the reduced camera system and factors it (default);
     solver="pcg" solves it by preconditioned conjugate gradients on the implicit Schur complement
     (sfm_ba_solve_pcg): no n x n matrix, one n-vector exchanged per iteration between ranks.
+    camera_solver (solver="dense" only): how the formed system is solved - "auto" (default): conjugate gradients on
+    the block-scaled system when n <= 4096 (one launch per iteration, Cholesky fallback), else the bordered
+    Cholesky; "cholesky" / "cg" force one.
     """
 
     def __init__(self, cams, pts, cam_idx, pt_idx, uv, K0, width=1024.0, height=768.0,
                  reg_weight=0.1, device=0, comm=None, precision="fp64", solver="dense", pcg_rtol=1e-13,
-                 pcg_max_iter=None):
+                 pcg_max_iter=None, camera_solver="auto"):
         import torch
         self.torch = torch
         self.comm = comm or LocalComm()
@@ -55,6 +58,9 @@ class GpuBA:
         if solver not in ("dense", "pcg"):
             raise ValueError(f"unknown solver {solver!r}")
         self.solver, self.pcg_rtol, self.pcg_max_iter = solver, float(pcg_rtol), pcg_max_iter
+        if camera_solver not in ("auto", "cholesky", "cg"):
+            raise ValueError(f"unknown camera_solver {camera_solver!r}")
+        self.camera_solver = camera_solver
         self.cg_iters = 0
         ci = np.ascontiguousarray(cam_idx, dtype=np.int32)
         pi = np.ascontiguousarray(pt_idx, dtype=np.int32)
@@ -74,6 +80,7 @@ class GpuBA:
         d.fx0, d.fy0, d.cx0, d.cy0 = (float(v) for v in K0)
         d.width, d.height, d.reg_weight = float(width), float(height), float(reg_weight)
         d.precision = _lib.PREC_MIXED if precision == "mixed" else _lib.PREC_FP64
+        d.camera_solver = {"auto": _lib.CAMERA_AUTO, "cholesky": _lib.CAMERA_CHOLESKY, "cg": _lib.CAMERA_CG}[camera_solver]
         self.desc = d
         self._pp = _lib.vp()
         rc = self.h.lib.sfm_ba_create_problem(self.h._h, C.byref(d), C.byref(self._pp))
@@ -103,6 +110,12 @@ class GpuBA:
                 self._pp = _lib.vp()
         except Exception:
             pass
+
+    def solver_stats(self):
+        """(CG iterations, fallbacks to the factorisation) of the camera_solver="cg" route so far."""
+        a, b = C.c_int64(0), C.c_int64(0)
+        self.h.lib.sfm_ba_solver_stats(self._pp, C.byref(a), C.byref(b))
+        return a.value, b.value
 
     # ---- structure (inspection / tests)
     def structure(self):

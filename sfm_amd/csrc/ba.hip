@@ -1120,6 +1120,236 @@ static int pack_S(sfm_handle h, sfm_ba_problem p, int unpack_dir, const char* wh
 extern "C" int sfm_ba_pack_system(sfm_handle h, sfm_ba_problem p) { return pack_S(h, p, 0, "sfm_ba_pack_system"); }
 extern "C" int sfm_ba_unpack_system(sfm_handle h, sfm_ba_problem p) { return pack_S(h, p, 1, "sfm_ba_unpack_system"); }
 
+// (defined with the implicit-Schur PCG further down)
+__global__ void k_dot(int n, const double* __restrict__ a, const double* __restrict__ b, double* __restrict__ out);
+__global__ void k_finish_solve_pcg(int n, const double* __restrict__ pc, const double* __restrict__ red_q, int want_q,
+                                   const double* __restrict__ dotp, const double* __restrict__ failp, double* __restrict__ sc);
+
+// ------------------------------------------------------------------------------------ CG on the explicit reduced system
+// Once S has been formed (and, multi-rank, all-reduced) the replicated camera solve is a latency chain in the dense
+// Cholesky (n / 64 dependent steps, 0.9 ms at n = 2000) - but with its own d x d diagonal blocks as preconditioner
+// S needs only ~25 conjugate-gradient iterations to a relative residual of 1e-13, each ONE launch that streams S once
+// from L2.  The system is scaled symmetrically with the Cholesky factors E_c of its diagonal blocks,
+// S~ = E^-1 (S + alpha I) E^-T (unit diagonal blocks), so that plain CG on S~ IS block-Jacobi PCG on S and the
+// recurrences need no preconditioner application.  k_cgs_iter: every workgroup first repeats the vector
+// recurrences of the previous iteration from r, p and the full S~ p (3 n doubles from L2, fixed-order block sums:
+// all workgroups obtain bit-identical scalars and vectors, so no grid-wide reduction or second launch is needed),
+// keeps the new direction in LDS and multiplies its own rows of S~ with it.  r, p, S~ p are double-buffered
+// (workgroup 0 publishes iteration k's vectors while others may still read iteration k-1's).  Rows are dealt to
+// workgroups so that one XCD owns a contiguous eighth of S~ (4 MB at n = 2000: stays in its L2 across iterations).
+// The host reads ||r||^2 every few launches.  If CG has not converged after CGS_MAX_ITER iterations, or meets a
+// direction of non-positive curvature, the caller falls back to the Cholesky route: S itself is left untouched.
+constexpr int CGS_MAX_N = 4096;          // the direction vector lives in LDS (32 KB); larger systems use the factorisation
+constexpr int CGS_ROWS = 8;              // rows of S~ per workgroup
+constexpr int CGS_MAX_ITER = 160;
+constexpr double CGS_RTOL = 1e-13;       // ||r|| <= CGS_RTOL ||r_0|| on the scaled system
+enum { CGS_RR0 = 0, CGS_RR = 1, CGS_ITER = 2, CGS_FAIL = 3, CGS_DONE = 4 };
+
+// E_c = chol(S_cc + alpha I); Einv[c] = E_c^-1 (lower, zeros above).  One thread per camera.
+template <int D>
+__global__ void k_diag_einv(int C, const double* __restrict__ S, int n, double alpha, double* __restrict__ Einv,
+                            double* __restrict__ scal) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  double L[D][D], X[D][D];
+  const double* blk = S + (size_t)c * D * n + c * D;
+#pragma unroll
+  for (int i = 0; i < D; ++i)
+#pragma unroll
+    for (int j = 0; j < D; ++j) L[i][j] = (j <= i) ? blk[(size_t)i * n + j] + (i == j ? alpha : 0.0) : 0.0;
+  bool bad = false;
+#pragma unroll
+  for (int j = 0; j < D; ++j) {
+    double sum = L[j][j];
+#pragma unroll
+    for (int k = 0; k < j; ++k) sum -= L[j][k] * L[j][k];
+    if (!(sum > 0.0)) { bad = true; sum = 1.0; }
+    const double l = sqrt(sum);
+    L[j][j] = l;
+#pragma unroll
+    for (int i = j + 1; i < D; ++i) {
+      double t = L[i][j];
+#pragma unroll
+      for (int k = 0; k < j; ++k) t -= L[i][k] * L[j][k];
+      L[i][j] = t / l;
+    }
+  }
+#pragma unroll
+  for (int t = 0; t < D; ++t)
+#pragma unroll
+    for (int r = 0; r < D; ++r) {
+      double sum = (r == t) ? 1.0 : 0.0;
+#pragma unroll
+      for (int k = 0; k < r; ++k) sum -= (k >= t ? L[r][k] * X[k][t] : 0.0);
+      X[r][t] = (r >= t) ? sum / L[r][r] : 0.0;
+    }
+#pragma unroll
+  for (int i = 0; i < D; ++i)
+#pragma unroll
+    for (int j = 0; j < D; ++j) Einv[(size_t)c * D * D + i * D + j] = X[i][j];
+  if (bad) scal[CGS_FAIL] = 1.0;
+}
+// St[c][c2] = Einv_c (S[c][c2] + alpha [c == c2]) Einv_c2^T, one workgroup (128 threads) per block pair, both triangles
+template <int D>
+__global__ __launch_bounds__(128) void k_scale_system(int n, const double* __restrict__ S, double alpha,
+                                                      const double* __restrict__ Einv, double* __restrict__ St) {
+  __shared__ double sB[D * D], sT[D * D], sE1[D * D], sE2[D * D];
+  const int c = blockIdx.x, c2 = blockIdx.y, e = threadIdx.x;
+  const int a = e / D, b = e - a * D;
+  if (e < D * D) {
+    // only the lower triangle of S is read: it is the part the multi-rank exchange carries (sfm_ba_pack_system)
+    const int row = c * D + a, col = c2 * D + b;
+    sB[e] = (col <= row ? S[(size_t)row * n + col] : S[(size_t)col * n + row]) + ((c == c2 && a == b) ? alpha : 0.0);
+    sE1[e] = Einv[(size_t)c * D * D + e];
+    sE2[e] = Einv[(size_t)c2 * D * D + e];
+  }
+  __syncthreads();
+  if (e < D * D) {
+    double t = 0.0;
+#pragma unroll
+    for (int k = 0; k < D; ++k) t += sE1[a * D + k] * sB[k * D + b];        // Einv_c is lower: entries k > a are stored zeros
+    sT[e] = t;
+  }
+  __syncthreads();
+  if (e < D * D) {
+    double t = 0.0;
+#pragma unroll
+    for (int k = 0; k < D; ++k) t += sT[a * D + k] * sE2[b * D + k];
+    St[(size_t)(c * D + a) * n + c2 * D + b] = t;
+  }
+}
+// out_c = Einv_c v_c (transpose 0) or Einv_c^T v_c (transpose 1), optionally negated
+template <int D>
+__global__ void k_block_mv(int C, const double* __restrict__ Einv, const double* __restrict__ v, double* __restrict__ out,
+                           int transpose, double sgn) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= C * D) return;
+  const int c = i / D, a = i - c * D;
+  const double* E = Einv + (size_t)c * D * D;
+  double t = 0.0;
+#pragma unroll
+  for (int k = 0; k < D; ++k) t += (transpose ? E[k * D + a] : E[a * D + k]) * v[c * D + k];
+  out[i] = sgn * t;
+}
+// state 0 of the recurrence: x = 0, r = p = rhs; rr0
+__global__ __launch_bounds__(256) void k_cgs_init(int n, const double* __restrict__ rhs, double* __restrict__ x,
+                                                  double* __restrict__ r0, double* __restrict__ p0, double* __restrict__ scal) {
+  __shared__ double s_red[4];
+  double rr = 0.0;
+  for (int i = threadIdx.x; i < n; i += 256) { const double v = rhs[i]; x[i] = 0.0; r0[i] = v; p0[i] = v; rr += v * v; }
+  rr = block_sum256(rr, s_red);
+  if (threadIdx.x == 0) { scal[CGS_RR0] = rr; scal[CGS_RR] = rr; scal[CGS_ITER] = 0.0; scal[CGS_DONE] = 0.0; }
+}
+// One CG iteration on S~ per launch.  it == 0: only the product S~ p_0.  vec: [2 states][r | p | Ap], n doubles each.
+__global__ __launch_bounds__(256) void k_cgs_iter(int n, int it, double rtol2, const double* __restrict__ St,
+                                                  double* __restrict__ vec, double* __restrict__ x, double* __restrict__ scal) {
+  __shared__ double s_p[CGS_MAX_N];
+  __shared__ double s_red[4];
+  __shared__ double s_row[CGS_ROWS][4];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const size_t sz = (size_t)3 * n;
+  const double* in = vec + (size_t)((it + 1) & 1) * sz;        // state written by launch it - 1 (it == 0: state 0 below)
+  double* out = vec + (size_t)(it & 1) * sz;
+  if (it == 0) {
+    in = vec;                                                  // k_cgs_init left r_0 = p_0 in state 0
+    for (int i = tid; i < n; i += 256) s_p[i] = in[n + i];
+  } else {
+    const double *r = in, *pv = in + n, *Ap = in + 2 * n;
+    constexpr int PER = CGS_MAX_N / 256;
+    double rv[PER], pvv[PER], av[PER];
+    double rr_old = 0.0, pAp = 0.0;
+#pragma unroll
+    for (int q = 0; q < PER; ++q) {
+      const int i = tid + 256 * q;
+      rv[q] = i < n ? r[i] : 0.0; pvv[q] = i < n ? pv[i] : 0.0; av[q] = i < n ? Ap[i] : 0.0;
+      rr_old += rv[q] * rv[q]; pAp += pvv[q] * av[q];
+    }
+    rr_old = block_sum256(rr_old, s_red);
+    pAp = block_sum256(pAp, s_red);
+    const double rr0 = scal[CGS_RR0];
+    const bool done = rr_old <= rtol2 * rr0;
+    const bool broken = !done && !(pAp > 0.0);                 // non-positive curvature (or NaN): S~ is not positive definite
+    if (done || broken) {
+      // carry the state forward unchanged so that later launches of this batch see it again (and stop again)
+      if (blockIdx.x == 0) {
+#pragma unroll
+        for (int q = 0; q < PER; ++q) { const int i = tid + 256 * q; if (i < n) { out[i] = rv[q]; out[n + i] = pvv[q]; out[2 * n + i] = av[q]; } }
+        if (tid == 0) { scal[CGS_RR] = rr_old; scal[CGS_DONE] = 1.0; if (broken) scal[CGS_FAIL] = 2.0; }
+      }
+      return;
+    }
+    const double a = rr_old / pAp;
+    double rr_new = 0.0;
+#pragma unroll
+    for (int q = 0; q < PER; ++q) { rv[q] -= a * av[q]; rr_new += rv[q] * rv[q]; }
+    rr_new = block_sum256(rr_new, s_red);
+    const double beta = rr_new / rr_old;
+#pragma unroll
+    for (int q = 0; q < PER; ++q) {
+      const int i = tid + 256 * q;
+      const double pn = rv[q] + beta * pvv[q];
+      if (i < n) {
+        s_p[i] = pn;
+        if (blockIdx.x == 0) { x[i] += a * pvv[q]; out[i] = rv[q]; out[n + i] = pn; }
+      }
+    }
+    if (blockIdx.x == 0 && tid == 0) { scal[CGS_RR] = rr_new; scal[CGS_ITER] = (double)it; }
+  }
+  __syncthreads();
+  // rows of this workgroup: XCD x = blockIdx % 8 owns rows [x * per_xcd, (x + 1) * per_xcd)
+  const int per_xcd = (int)(gridDim.x / 8) * CGS_ROWS;
+  const int row0 = (int)(blockIdx.x & 7) * per_xcd + (int)(blockIdx.x >> 3) * CGS_ROWS;
+  double acc[CGS_ROWS];
+#pragma unroll
+  for (int q = 0; q < CGS_ROWS; ++q) acc[q] = 0.0;
+  const int n2 = n & ~1;
+  for (int j = 2 * tid; j < n2; j += 512) {
+    const double p0 = s_p[j], p1 = s_p[j + 1];
+#pragma unroll
+    for (int q = 0; q < CGS_ROWS; ++q) {
+      const int row = row0 + q;
+      if (row < n) {
+        const double2 sv = *(const double2*)(St + (size_t)row * n + j);
+        acc[q] += sv.x * p0 + sv.y * p1;
+      }
+    }
+  }
+  if ((n & 1) && tid == 0) {
+#pragma unroll
+    for (int q = 0; q < CGS_ROWS; ++q) if (row0 + q < n) acc[q] += St[(size_t)(row0 + q) * n + n - 1] * s_p[n - 1];
+  }
+#pragma unroll
+  for (int q = 0; q < CGS_ROWS; ++q) {
+    const double t = wave_sum(acc[q]);
+    if (lane == 0) s_row[q][w] = t;
+  }
+  __syncthreads();
+  if (tid < CGS_ROWS && row0 + tid < n) out[2 * n + row0 + tid] = (s_row[tid][0] + s_row[tid][1]) + (s_row[tid][2] + s_row[tid][3]);
+}
+
+// x~ = S~^-1 rhs~ by CG; returns 0 converged / 1 not converged or broken (caller falls back to the factorisation)
+static int cgs_solve(sfm_ctx* h, int n, const double* St, const double* rhs_t, double* x_t, double* vec, double* scal,
+                     double rtol, int* iters_out, int* status) {
+  const int per_xcd_wg = (int)cdiv(cdiv(n, 8), CGS_ROWS);
+  const unsigned grid = 8u * (unsigned)per_xcd_wg;
+  hipLaunchKernelGGL(k_cgs_init, dim3(1), dim3(256), 0, h->stream, n, rhs_t, x_t, vec, vec + n, scal);
+  int it = 0;
+  *status = 1;
+  const double rtol2 = rtol * rtol;
+  while (it <= CGS_MAX_ITER) {
+    const int batch = it == 0 ? 17 : 8;                           // first look after 16 iterations, then every 8
+    for (int b = 0; b < batch; ++b, ++it)
+      hipLaunchKernelGGL(k_cgs_iter, dim3(grid), dim3(256), 0, h->stream, n, it, rtol2, St, vec, x_t, scal);
+    SFM_HIP(h, hipMemcpyAsync(h->pinned, scal, 8 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    SFM_HIP(h, hipStreamSynchronize(h->stream));
+    if (h->pinned[CGS_FAIL] != 0.0) break;
+    if (h->pinned[CGS_DONE] != 0.0 || h->pinned[CGS_RR] <= rtol2 * h->pinned[CGS_RR0]) { *status = 0; break; }
+  }
+  *iters_out += (int)h->pinned[CGS_ITER];
+  SFM_LAUNCH_CHECK(h, "cgs_solve");
+  return SFM_OK;
+}
+
 extern "C" int sfm_ba_schur_solve(sfm_handle h, sfm_ba_problem p, double alpha, int want_q) {
   Lay L; int rc = check_problem(h, p, &L); if (rc) return rc;
   double* ws = (double*)p->workspace;
@@ -1128,15 +1358,39 @@ extern "C" int sfm_ba_schur_solve(sfm_handle h, sfm_ba_problem p, double alpha, 
   double* S = WS(L, red_S);
   DenseWs dw; dense_ws_carve(WS(L, dense), n, &dw);
   SFM_HIP(h, hipMemsetAsync(dw.flag, 0, sizeof(int), h->stream));
-  sfm_prof_begin(h, SFM_PROF_CHOL);
-  hipLaunchKernelGGL(k_add_diag, dim3(cdiv(n, 256)), dim3(256), 0, h->stream, S, n, alpha);
-  rc = dense_cholesky(h, S, n, n + 1, dw); if (rc) return rc;   // row n: r -> L^-1 r
-  sfm_prof_end(h, SFM_PROF_CHOL);
-  sfm_prof_begin(h, SFM_PROF_TRSV);
-  // p_c = -L^-T (L^-1 r)
-  hipLaunchKernelGGL(k_copy_neg, dim3(cdiv(n, 256)), dim3(256), 0, h->stream, dw.Lm + (size_t)n * n, WS(L, tvec), n, -1.0);
-  rc = dense_trsv(h, n, dw, WS(L, tvec), WS(L, pc), 1); if (rc) return rc;
-  sfm_prof_end(h, SFM_PROF_TRSV);
+  p->cg_state = 0;
+  p->cg_alpha = alpha;
+  if (p->camera_solver != SFM_CAMERA_SOLVER_CHOLESKY && n <= CGS_MAX_N && (n & 1) == 0) {
+    // S~ = E^-1 (S + alpha I) E^-T into the factor's buffer (S stays as it is: the fallback below needs it), r~ = E^-1 r
+    sfm_prof_begin(h, SFM_PROF_CHOL);
+    SFM_HIP(h, hipMemsetAsync(WS(L, cg_scal), 0, 16 * sizeof(double), h->stream));
+    DISPATCH_D(D, {
+      hipLaunchKernelGGL(k_diag_einv<DD>, dim3(cdiv(C, 64)), dim3(64), 0, h->stream, C, S, n, alpha, WS(L, cg_Minv), WS(L, cg_scal));
+      hipLaunchKernelGGL(k_scale_system<DD>, dim3(C, C), dim3(128), 0, h->stream, n, S, alpha, WS(L, cg_Minv), dw.Lm);
+      hipLaunchKernelGGL(k_block_mv<DD>, dim3(cdiv(n, 256)), dim3(256), 0, h->stream, C, WS(L, cg_Minv), S + (size_t)n * n, WS(L, cg_r), 0, 1.0);
+    });
+    int status = 1;
+    rc = cgs_solve(h, n, dw.Lm, WS(L, cg_r), WS(L, cg_z), dw.LmT, WS(L, cg_scal), CGS_RTOL, &p->cg_iters, &status); if (rc) return rc;
+    if (status == 0) {
+      DISPATCH_D(D, hipLaunchKernelGGL(k_block_mv<DD>, dim3(cdiv(n, 256)), dim3(256), 0, h->stream, C, WS(L, cg_Minv), WS(L, cg_z),
+                                       WS(L, pc), 1, -1.0));                      // p_c = -E^-T x~
+      p->cg_state = 1;
+    } else {
+      p->cg_fallbacks++;
+    }
+    sfm_prof_end(h, SFM_PROF_CHOL);
+  }
+  if (p->cg_state == 0) {
+    sfm_prof_begin(h, SFM_PROF_CHOL);
+    hipLaunchKernelGGL(k_add_diag, dim3(cdiv(n, 256)), dim3(256), 0, h->stream, S, n, alpha);
+    rc = dense_cholesky(h, S, n, n + 1, dw); if (rc) return rc;   // row n: r -> L^-1 r
+    sfm_prof_end(h, SFM_PROF_CHOL);
+    sfm_prof_begin(h, SFM_PROF_TRSV);
+    // p_c = -L^-T (L^-1 r)
+    hipLaunchKernelGGL(k_copy_neg, dim3(cdiv(n, 256)), dim3(256), 0, h->stream, dw.Lm + (size_t)n * n, WS(L, tvec), n, -1.0);
+    rc = dense_trsv(h, n, dw, WS(L, tvec), WS(L, pc), 1); if (rc) return rc;
+    sfm_prof_end(h, SFM_PROF_TRSV);
+  }
   sfm_prof_begin(h, SFM_PROF_BACKSUB);
   DISPATCH_DT(D, p->precision, hipLaunchKernelGGL((k_obs_Gtp<DD, double, GG>), dim3(cdiv(N * 3, 256)), dim3(256), 0, h->stream, N * 3,
                                                   p->cam_idx, WS(L, G), WS(L, pc), WS(L, tmp3)));
@@ -1163,6 +1417,35 @@ extern "C" int sfm_ba_finish_solve(sfm_handle h, sfm_ba_problem p, int want_q) {
   double* ws = (double*)p->workspace;
   const int n = p->n_cams * p->cam_dim;
   DenseWs dw; dense_ws_carve(WS(L, dense), n, &dw);
+  if (p->cg_state == 1) {
+    // the camera system was solved by CG on the scaled system S~ (still in dw.Lm): p^T (H + alpha I)^-1 p needs
+    // rhs2^T S^-1 rhs2 = r~2^T x~2 with r~2 = E^-1 rhs2, S~ x~2 = r~2
+    const int C = p->n_cams, D = p->cam_dim;
+    int status = 0;
+    if (want_q) {
+      sfm_prof_begin(h, SFM_PROF_TRSV);
+      hipLaunchKernelGGL(k_add_vec, dim3(cdiv(n, 256)), dim3(256), 0, h->stream, WS(L, pc), WS(L, red_q), WS(L, tvec), n);
+      DISPATCH_D(D, hipLaunchKernelGGL(k_block_mv<DD>, dim3(cdiv(n, 256)), dim3(256), 0, h->stream, C, WS(L, cg_Minv), WS(L, tvec),
+                                       WS(L, cg_r), 0, 1.0));
+      status = 1;
+      rc = cgs_solve(h, n, dw.Lm, WS(L, cg_r), WS(L, cg_z), dw.LmT, WS(L, cg_scal), CGS_RTOL, &p->cg_iters, &status); if (rc) return rc;
+      if (status == 0)
+        hipLaunchKernelGGL(k_dot, dim3(1), dim3(1024), 0, h->stream, n, WS(L, cg_r), WS(L, cg_z), WS(L, cg_scal) + 8);
+      sfm_prof_end(h, SFM_PROF_TRSV);
+    }
+    if (status == 0) {
+      hipLaunchKernelGGL(k_finish_solve_pcg, dim3(1), dim3(256), 0, h->stream, n, WS(L, pc), WS(L, red_q), want_q, WS(L, cg_scal) + 8,
+                         WS(L, cg_scal) + CGS_FAIL, WS(L, scalars));
+      SFM_LAUNCH_CHECK(h, "sfm_ba_finish_solve");
+      return SFM_OK;
+    }
+    // the second system did not converge: factor after all (S is intact) and take the q term from the factor
+    p->cg_fallbacks++;
+    p->cg_state = 0;
+    SFM_HIP(h, hipMemsetAsync(dw.flag, 0, sizeof(int), h->stream));
+    hipLaunchKernelGGL(k_add_diag, dim3(cdiv(n, 256)), dim3(256), 0, h->stream, WS(L, red_S), n, p->cg_alpha);
+    rc = dense_cholesky(h, WS(L, red_S), n, n + 1, dw); if (rc) return rc;
+  }
   if (want_q) {
     // rhs2 = p_c - W C_a^-1 p_p ;  y = L^-1 rhs2
     sfm_prof_begin(h, SFM_PROF_TRSV);
@@ -1363,15 +1646,16 @@ __global__ __launch_bounds__(1024) void k_dot(int n, const double* __restrict__ 
 }
 // scalars after a PCG solve: PNORM2 = ||p_c||^2 + sum ||p_p||^2, PQ = rhs2^T S^-1 rhs2 + sum ||v||^2, failure code
 __global__ __launch_bounds__(256) void k_finish_solve_pcg(int n, const double* __restrict__ pc, const double* __restrict__ red_q,
-                                                          int want_q, const double* __restrict__ cg_scal, double* __restrict__ sc) {
+                                                          int want_q, const double* __restrict__ dotp, const double* __restrict__ failp,
+                                                          double* __restrict__ sc) {
   __shared__ double s_red[4];
   double a = 0.0;
   for (int i = threadIdx.x; i < n; i += 256) a += pc[i] * pc[i];
   const double at = block_sum256(a, s_red);
   if (threadIdx.x == 0) {
-    const double pn2 = at + red_q[n], pq = want_q ? (cg_scal[CG_DOT] + red_q[n + 1]) : 0.0;
+    const double pn2 = at + red_q[n], pq = want_q ? (*dotp + red_q[n + 1]) : 0.0;
     sc[SFM_SC_PNORM2] = pn2; sc[SFM_SC_PQ] = pq;
-    double f = cg_scal[CG_FAIL] != 0.0 ? 1.0 : 0.0;        // 1: a block or S itself is not positive definite
+    double f = *failp != 0.0 ? 1.0 : 0.0;                   // 1: a block or S itself is not positive definite
     if (f == 0.0 && !(isfinite(pn2) && isfinite(pq))) f = 3.0;
     sc[SFM_SC_CHOL_FAIL] = f;
   }
@@ -1490,7 +1774,8 @@ extern "C" int sfm_ba_solve_pcg(sfm_handle h, sfm_ba_problem p, double alpha, in
     hipLaunchKernelGGL(k_dot, dim3(1), dim3(1024), 0, h->stream, n, WS(L, tvec), WS(L, y), WS(L, cg_scal) + CG_DOT);
     sfm_prof_end(h, SFM_PROF_TRSV);
   }
-  hipLaunchKernelGGL(k_finish_solve_pcg, dim3(1), dim3(256), 0, h->stream, n, WS(L, pc), WS(L, red_q), want_q, WS(L, cg_scal), WS(L, scalars));
+  hipLaunchKernelGGL(k_finish_solve_pcg, dim3(1), dim3(256), 0, h->stream, n, WS(L, pc), WS(L, red_q), want_q, WS(L, cg_scal) + CG_DOT,
+                     WS(L, cg_scal) + CG_FAIL, WS(L, scalars));
   SFM_LAUNCH_CHECK(h, "sfm_ba_solve_pcg");
   if (iters_host) *iters_host = cg.iters;
   return SFM_OK;

@@ -30,6 +30,11 @@ struct sfm_ba_prob {
   int64_t workspace_bytes;
   int owns_workspace;
   Lay L;
+  // camera-system solver (sfm_ba_desc.camera_solver) and the state of the current damped solve between
+  // sfm_ba_schur_solve and sfm_ba_finish_solve: cg_state 1 = p_c came from CG on the scaled system (still in the
+  // factor's buffer), 0 = from the factorisation
+  int camera_solver, cg_state, cg_iters, cg_fallbacks;
+  double cg_alpha;
 };
 
 Lay ba_layout(int64_t C, int64_t P, int64_t N, int64_t D, int64_t n_items, int64_t n_cchunks, int precision);

@@ -176,6 +176,8 @@ extern "C" int sfm_ba_create_problem(sfm_handle h, const sfm_ba_desc* d, sfm_ba_
   if (d->n_obs >= (1ll << 31)) return sfm_fail(h, SFM_ERR_ARG, "sfm_ba_create_problem", "too many observations for int32 indices");
   if (d->precision != SFM_BA_FP64 && d->precision != SFM_BA_MIXED)
     return sfm_fail(h, SFM_ERR_ARG, "sfm_ba_create_problem", "unknown precision");
+  if (d->camera_solver < SFM_CAMERA_SOLVER_AUTO || d->camera_solver > SFM_CAMERA_SOLVER_CG)
+    return sfm_fail(h, SFM_ERR_ARG, "sfm_ba_create_problem", "unknown camera_solver");
   const int C = d->n_cams, P = d->n_pts;
   const int64_t N = d->n_obs;
   const int64_t n_blk = (int64_t)C * (C + 1) / 2;
@@ -185,6 +187,7 @@ extern "C" int sfm_ba_create_problem(sfm_handle h, const sfm_ba_desc* d, sfm_ba_
   memset(p, 0, sizeof(*p));
   p->h = h;
   p->n_cams = C; p->n_pts = P; p->cam_dim = d->cam_dim; p->apply_reg = d->apply_reg; p->precision = d->precision;
+  p->camera_solver = d->camera_solver;
   p->n_obs = N;
   p->fx0 = d->fx0; p->fy0 = d->fy0; p->cx0 = d->cx0; p->cy0 = d->cy0;
   p->width = d->width; p->height = d->height; p->reg_weight = d->reg_weight;
@@ -343,6 +346,12 @@ extern "C" int sfm_ba_create_problem(sfm_handle h, const sfm_ba_desc* d, sfm_ba_
   }
   p->L = ba_layout(C, P, N, d->cam_dim, p->n_items, p->n_cchunks, p->precision);
   *out = p;
+  return SFM_OK;
+}
+
+extern "C" int sfm_ba_solver_stats(sfm_ba_problem p, int64_t* cg_iters, int64_t* cg_fallbacks) {
+  if (!p || !cg_iters || !cg_fallbacks) return SFM_ERR_ARG;
+  *cg_iters = p->cg_iters; *cg_fallbacks = p->cg_fallbacks;
   return SFM_OK;
 }
 

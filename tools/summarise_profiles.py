@@ -85,10 +85,11 @@ if m:
         for c in sorted(m):
             fh.write(f"{c:32s} n={len(m[c]):3d} mean={sum(m[c]) / len(m[c]):16.1f}\n")
         g = lambda c: sum(m[c]) / len(m[c]) if m.get(c) else float("nan")
-        # the SQ counters of this pool cover ONE XCD (32 CUs = 128 SIMDs): 1/8 of the kernel's instructions; GRBM_GUI_ACTIVE is
-        # the kernel's duration in cycles.  SQ_ACTIVE_INST_* count quad-cycles, SQ_VALU_MFMA_BUSY_CYCLES cycles (MI355X_MICROARCH.md)
-        simd_cycles = g('GRBM_GUI_ACTIVE') * 128
+        # SQ counters are chip-wide sums (SQ_WAVES = every wave of the launch); GRBM_GUI_ACTIVE is summed over the 8 XCDs, so
+        # the SIMD-cycles of the launch are (GRBM_GUI_ACTIVE / 8) * 1024.  SQ_ACTIVE_INST_* count quad-cycles,
+        # SQ_VALU_MFMA_BUSY_CYCLES cycles (MI355X_MICROARCH.md)
+        simd_cycles = g('GRBM_GUI_ACTIVE') / 8 * 1024
         fh.write(f"# VALU instructions per MFMA: {g('SQ_INSTS_VALU') / g('SQ_INSTS_MFMA'):.2f}\n")
-        fh.write(f"# MFMA pipe busy: {g('SQ_VALU_MFMA_BUSY_CYCLES') / simd_cycles:.3f} of the SIMD-cycles of the sampled XCD\n")
+        fh.write(f"# MFMA pipe busy: {g('SQ_VALU_MFMA_BUSY_CYCLES') / simd_cycles:.3f} of the launch's SIMD-cycles\n")
         fh.write(f"# VALU busy: {4 * g('SQ_ACTIVE_INST_VALU') / simd_cycles:.3f}; LDS bank conflicts: {g('SQ_LDS_BANK_CONFLICT'):.0f}\n")
     print(open(os.path.join(dst, f"{rnd}_pmc_matcher.txt")).read())
