@@ -187,18 +187,42 @@ def main():
         return r
 
     bytes_per_obs = 8 + 16 + 16 + 2 * d * 8 + 48
-    roofs = [
-        roof("k_chol_diag + k_chol_step (+ k_syrk_lower): bordered Cholesky of the reduced camera system, n = %d" % n_sys,
-             "mfma", n_sys ** 3 / 3.0, 1e12, FP64_MFMA_PEAK_TFLOPS, "TFLOP/s", "chol",
-             note=("latency chain of %d dependent 64-column steps" % ((n_sys + 63) // 64)) if n_sys < 4096
-             else "256-column strips + rank-256 trailing updates"),
-        roof("k_schur_items (S blocks = -sum G_k G_k2^T per camera pair) + assemble + rhs", "hbm",
-             2.0 * main["n_pairs"] * 3 * d * 8, 1e9, HBM_PEAK_GBS, "GB/s", "schur", "k_schur_items",
-             note="gather through L2 / Infinity Cache: bytes are the G blocks pulled per launch, not unique HBM bytes"),
+    cg_on = args.camera_solver != "cholesky" and n_sys <= 4096
+    cam_roofs = []
+    if cg_on and "chol" in kernels:
+        # both slots of the camera solve hold CG solves here (chol: the step system, trsv: the system of the q term)
+        its, fb = profd["camera_cg"]
+        n_systems = kernels["chol"]["launches"] + kernels.get("trsv", {}).get("launches", 0)
+        per_system = its / max(n_systems, 1)
+        cam_roofs.append(roof("k_cgs_iter: CG on the block-scaled camera system, n = %d (one launch per iteration)" % n_sys, "hbm",
+                              per_system * n_sys * n_sys * 8.0, 1e9, HBM_PEAK_GBS, "GB/s", "chol",
+                              note="%.1f iterations per system on average (relative residual 1e-13), each streams S~ (n^2 doubles, "
+                                   "L2 / Infinity-Cache resident) once: launch-latency bound, ~8 us per iteration; %d fallbacks to "
+                                   "the factorisation" % (per_system, fb)))
+    else:
+        cam_roofs.append(roof("k_chol_diag + k_chol_step (+ k_syrk_lower): bordered Cholesky of the reduced camera system, n = %d" % n_sys,
+                              "mfma", n_sys ** 3 / 3.0, 1e12, FP64_MFMA_PEAK_TFLOPS, "TFLOP/s", "chol",
+                              note=("latency chain of %d dependent 64-column steps" % ((n_sys + 63) // 64)) if n_sys < 4096
+                              else "256-column strips + rank-256 trailing updates"))
+    roofs = cam_roofs + [
+        roof("k_schur_items (S blocks = -sum G_k G_k2^T per camera pair, f64 MFMA)", "hbm",
+             2.0 * main["n_pairs"] * 3 * d * 8, 1e9, HBM_PEAK_GBS, "GB/s", "schur_items", "k_schur_items",
+             note="a gather: `achieved` counts the G blocks pulled per launch (2 x 240 B per camera pair, every block ~11 times), "
+                  "`traffic` what leaves the L2s for the Infinity Cache / HBM; the unique data is %.0f MB of G + %.0f MB of pair "
+                  "indices - see unique_bytes / refetch" % (main["n_obs_local"] * 3 * d * 8 / 1e6, main["n_pairs"] * 8 / 1e6)),
         roof("k_lin_obs (residual + 2x(%d+3) Jacobian + Huber scaling)" % d, "hbm", float(bytes_per_obs) * main["n_obs_local"],
              1e9, HBM_PEAK_GBS, "GB/s", "lin_obs", "k_lin_obs"),
     ]
     roofs = [r for r in roofs if r]
+    for r in roofs:
+        if r["kernel"].startswith("k_schur_items"):
+            r["unique_bytes"] = main["n_obs_local"] * 3 * d * 8 + main["n_pairs"] * 8
+            r["frac_unique_bytes"] = round(r["unique_bytes"] / (r["avg_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)
+            if r["traffic"]:
+                r["refetch"] = round(r["traffic"] / r["unique_bytes"], 2)
+            # the whole Schur stage (items + assemble + right-hand side) shares this entry's time share
+            r["time_share"] = kernels["schur"]["share"]
+            r["stage_us"] = kernels["schur"]["us_per_launch"]
     # headline roofline object = the kernel (group) with the largest share of the step time
     roofline = max(roofs, key=lambda r: r["time_share"]) if roofs else None
 

@@ -43,12 +43,13 @@ enum { SFM_PROF_LIN_OBS = 0,   /* k_lin_obs: residual + Jacobian + Huber scaling
        SFM_PROF_LIN_REST = 1,  /* per-point / per-camera block sums of a linearisation */
        SFM_PROF_BUILD_G = 2,   /* point factors + G = W L^-T */
        SFM_PROF_SCHUR = 3,     /* reduced camera system S, r */
-       SFM_PROF_CHOL = 4,      /* dense bordered Cholesky of S */
-       SFM_PROF_TRSV = 5,      /* triangular solves with the factor */
+       SFM_PROF_CHOL = 4,      /* camera solve for the step: CG on the scaled system, or the bordered Cholesky of S */
+       SFM_PROF_TRSV = 5,      /* second system (q term) by CG, or the triangular solves with the factor */
        SFM_PROF_BACKSUB = 6,   /* point back-substitution and the q pieces */
        SFM_PROF_STEP = 7,      /* trial step: x + s, predicted reduction sums, cost(x + s) */
        SFM_PROF_KNN = 8,       /* matcher distance + top-2 kernel */
-       SFM_PROF_COUNT = 9 };
+       SFM_PROF_SCHUR_ITEMS = 9, /* k_schur_items alone (inside SFM_PROF_SCHUR) */
+       SFM_PROF_COUNT = 10 };
 int sfm_set_profiling(sfm_handle h, int enabled);
 int sfm_profile_read(sfm_handle h, int slot, double* total_ms_host, int64_t* count_host);
 

@@ -12,7 +12,7 @@ METRIC_L2_U8, METRIC_L2_F32, METRIC_HAMMING = 0, 1, 2
 (SC_COST, SC_GNORM2, SC_GINF, SC_PNORM2, SC_PQ, SC_JS2, SC_GTS, SC_COST_NEW, SC_SNORM2,
  SC_XNEW_NORM2, SC_CHOL_FAIL, SC_HDIAG) = range(12)
 SC_COUNT = 16
-PROF_SLOTS = ("lin_obs", "lin_rest", "build_G", "schur", "chol", "trsv", "backsub", "step", "knn")
+PROF_SLOTS = ("lin_obs", "lin_rest", "build_G", "schur", "chol", "trsv", "backsub", "step", "knn", "schur_items")
 
 i32, i64, f64, vp = C.c_int32, C.c_int64, C.c_double, C.c_void_p
 

@@ -1080,9 +1080,12 @@ extern "C" int sfm_ba_schur_build(sfm_handle h, sfm_ba_problem p, double alpha) 
                        WST(L, recB), WS(L, Linv), WS(L, G));
     sfm_prof_end(h, SFM_PROF_BUILD_G);
     sfm_prof_begin(h, SFM_PROF_SCHUR);
-    if (p->n_items > 0)   // 8 groups x ceil(largest group / 4) workgroups
+    if (p->n_items > 0) { // 8 groups x ceil(largest group / 4) workgroups
+      sfm_prof_begin(h, SFM_PROF_SCHUR_ITEMS);
       hipLaunchKernelGGL((k_schur_items<DD, double, GG>), dim3(8 * cdiv(p->xcd_max_items, 4)), dim3(256), 0, h->stream,
                          p->xcd_ptr, p->xcd_items, p->item_beg, p->item_end, p->pair_k, p->pair_k2, WS(L, G), WS(L, sch_part));
+      sfm_prof_end(h, SFM_PROF_SCHUR_ITEMS);
+    }
     hipLaunchKernelGGL(k_schur_assemble<DD>, dim3(C, cdiv(C, 2)), dim3(256), 0, h->stream, C, p->item_ptr,
                        WS(L, sch_part), WS(L, B), WS(L, red_S));
     if (p->n_cchunks > 0)
