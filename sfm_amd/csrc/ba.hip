@@ -19,6 +19,7 @@
 //   S | r  [(n+1)][n] reduced camera system with its right-hand side as a bordered row
 // Observations of one point (a track) are contiguous; cameras are reached through cam_obs.
 #include "ba_internal.h"
+#include <cmath>
 
 typedef double v4d __attribute__((ext_vector_type(4)));
 
@@ -1143,10 +1144,10 @@ __global__ void k_finish_solve_pcg(int n, const double* __restrict__ pc, const d
 // The host reads ||r||^2 every few launches.  If CG has not converged after CGS_MAX_ITER iterations, or meets a
 // direction of non-positive curvature, the caller falls back to the Cholesky route: S itself is left untouched.
 constexpr int CGS_MAX_N = 4096;          // the direction vector lives in LDS (32 KB); larger systems use the factorisation
-constexpr int CGS_ROWS = 8;              // rows of S~ per workgroup
 constexpr int CGS_MAX_ITER = 160;
 constexpr double CGS_RTOL = 1e-13;       // ||r|| <= CGS_RTOL ||r_0|| on the scaled system
-enum { CGS_RR0 = 0, CGS_RR = 1, CGS_ITER = 2, CGS_FAIL = 3, CGS_DONE = 4 };
+enum { CGS_RR0 = 0, CGS_RR = 1, CGS_ITER = 2, CGS_FAIL = 3, CGS_DONE = 4,
+       CGS_RR_SLOT = 5 };   // [5], [6]: ||r||^2 handed from launch to launch; launch `it` reads slot (it + 1) & 1, writes slot it & 1
 
 // E_c = chol(S_cc + alpha I); Einv[c] = E_c^-1 (lower, zeros above).  One thread per camera.
 template <int D>
@@ -1241,35 +1242,54 @@ __global__ __launch_bounds__(256) void k_cgs_init(int n, const double* __restric
   double rr = 0.0;
   for (int i = threadIdx.x; i < n; i += 256) { const double v = rhs[i]; x[i] = 0.0; r0[i] = v; p0[i] = v; rr += v * v; }
   rr = block_sum256(rr, s_red);
-  if (threadIdx.x == 0) { scal[CGS_RR0] = rr; scal[CGS_RR] = rr; scal[CGS_ITER] = 0.0; scal[CGS_DONE] = 0.0; }
+  if (threadIdx.x == 0) {
+    scal[CGS_RR0] = rr; scal[CGS_RR] = rr; scal[CGS_ITER] = 0.0; scal[CGS_DONE] = 0.0;
+    scal[CGS_RR_SLOT] = rr; scal[CGS_RR_SLOT + 1] = rr;
+  }
 }
 // One CG iteration on S~ per launch.  it == 0: only the product S~ p_0.  vec: [2 states][r | p | Ap], n doubles each.
+// NC = ceil(n / 512) column chunks per thread, ROWS rows of S~ per workgroup.  The workgroup's slice of S~ does not
+// depend on the recurrences, so it is fetched into registers FIRST (ROWS x NC 16-byte loads per thread in flight)
+// and the vector recurrences run in the shadow of that latency; measured 12.8 -> ... us per launch.
+template <int NC, int ROWS>
 __global__ __launch_bounds__(256) void k_cgs_iter(int n, int it, double rtol2, const double* __restrict__ St,
                                                   double* __restrict__ vec, double* __restrict__ x, double* __restrict__ scal) {
-  __shared__ double s_p[CGS_MAX_N];
+  __shared__ double s_p[NC * 512];
   __shared__ double s_red[4];
-  __shared__ double s_row[CGS_ROWS][4];
+  __shared__ double s_row[ROWS][4];
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  // rows of this workgroup: XCD x = blockIdx % 8 owns rows [x * per_xcd, (x + 1) * per_xcd)
+  const int per_xcd = (int)(gridDim.x / 8) * ROWS;
+  const int row0 = (int)(blockIdx.x & 7) * per_xcd + (int)(blockIdx.x >> 3) * ROWS;
+  double2 sv[ROWS][NC];
+#pragma unroll
+  for (int q = 0; q < ROWS; ++q)
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+      const int row = row0 + q, jc = 2 * tid + 512 * c;            // n is even: jc < n implies jc + 1 < n
+      sv[q][c] = (row < n && jc < n) ? *(const double2*)(St + (size_t)row * n + jc) : make_double2(0.0, 0.0);
+    }
   const size_t sz = (size_t)3 * n;
   const double* in = vec + (size_t)((it + 1) & 1) * sz;        // state written by launch it - 1 (it == 0: state 0 below)
   double* out = vec + (size_t)(it & 1) * sz;
   if (it == 0) {
     in = vec;                                                  // k_cgs_init left r_0 = p_0 in state 0
-    for (int i = tid; i < n; i += 256) s_p[i] = in[n + i];
+    for (int i = tid; i < NC * 512; i += 256) s_p[i] = i < n ? in[n + i] : 0.0;
   } else {
     const double *r = in, *pv = in + n, *Ap = in + 2 * n;
-    constexpr int PER = CGS_MAX_N / 256;
+    constexpr int PER = 2 * NC;
     double rv[PER], pvv[PER], av[PER];
-    double rr_old = 0.0, pAp = 0.0;
+    double pAp = 0.0;
 #pragma unroll
     for (int q = 0; q < PER; ++q) {
       const int i = tid + 256 * q;
       rv[q] = i < n ? r[i] : 0.0; pvv[q] = i < n ? pv[i] : 0.0; av[q] = i < n ? Ap[i] : 0.0;
-      rr_old += rv[q] * rv[q]; pAp += pvv[q] * av[q];
+      pAp += pvv[q] * av[q];
     }
-    rr_old = block_sum256(rr_old, s_red);
     pAp = block_sum256(pAp, s_red);
-    const double rr0 = scal[CGS_RR0];
+    // ||r||^2 as workgroup 0 of the previous launch left it.  It writes the new value to the OTHER slot: workgroups of
+    // this launch that run later must still find the old one
+    const double rr_old = scal[CGS_RR_SLOT + ((it + 1) & 1)], rr0 = scal[CGS_RR0];
     const bool done = rr_old <= rtol2 * rr0;
     const bool broken = !done && !(pAp > 0.0);                 // non-positive curvature (or NaN): S~ is not positive definite
     if (done || broken) {
@@ -1277,7 +1297,7 @@ __global__ __launch_bounds__(256) void k_cgs_iter(int n, int it, double rtol2, c
       if (blockIdx.x == 0) {
 #pragma unroll
         for (int q = 0; q < PER; ++q) { const int i = tid + 256 * q; if (i < n) { out[i] = rv[q]; out[n + i] = pvv[q]; out[2 * n + i] = av[q]; } }
-        if (tid == 0) { scal[CGS_RR] = rr_old; scal[CGS_DONE] = 1.0; if (broken) scal[CGS_FAIL] = 2.0; }
+        if (tid == 0) { scal[CGS_RR_SLOT + (it & 1)] = rr_old; scal[CGS_DONE] = 1.0; if (broken) scal[CGS_FAIL] = 2.0; }
       }
       return;
     }
@@ -1291,62 +1311,62 @@ __global__ __launch_bounds__(256) void k_cgs_iter(int n, int it, double rtol2, c
     for (int q = 0; q < PER; ++q) {
       const int i = tid + 256 * q;
       const double pn = rv[q] + beta * pvv[q];
-      if (i < n) {
-        s_p[i] = pn;
-        if (blockIdx.x == 0) { x[i] += a * pvv[q]; out[i] = rv[q]; out[n + i] = pn; }
-      }
+      s_p[i] = i < n ? pn : 0.0;
+      if (i < n && blockIdx.x == 0) { x[i] += a * pvv[q]; out[i] = rv[q]; out[n + i] = pn; }
     }
-    if (blockIdx.x == 0 && tid == 0) { scal[CGS_RR] = rr_new; scal[CGS_ITER] = (double)it; }
+    if (blockIdx.x == 0 && tid == 0) { scal[CGS_RR_SLOT + (it & 1)] = rr_new; scal[CGS_RR] = rr_new; scal[CGS_ITER] = (double)it; }
   }
   __syncthreads();
-  // rows of this workgroup: XCD x = blockIdx % 8 owns rows [x * per_xcd, (x + 1) * per_xcd)
-  const int per_xcd = (int)(gridDim.x / 8) * CGS_ROWS;
-  const int row0 = (int)(blockIdx.x & 7) * per_xcd + (int)(blockIdx.x >> 3) * CGS_ROWS;
-  double acc[CGS_ROWS];
+  double acc[ROWS];
 #pragma unroll
-  for (int q = 0; q < CGS_ROWS; ++q) acc[q] = 0.0;
-  const int n2 = n & ~1;
-  for (int j = 2 * tid; j < n2; j += 512) {
-    const double p0 = s_p[j], p1 = s_p[j + 1];
+  for (int q = 0; q < ROWS; ++q) acc[q] = 0.0;
 #pragma unroll
-    for (int q = 0; q < CGS_ROWS; ++q) {
-      const int row = row0 + q;
-      if (row < n) {
-        const double2 sv = *(const double2*)(St + (size_t)row * n + j);
-        acc[q] += sv.x * p0 + sv.y * p1;
-      }
-    }
-  }
-  if ((n & 1) && tid == 0) {
+  for (int c = 0; c < NC; ++c) {
+    const double p0 = s_p[2 * tid + 512 * c], p1 = s_p[2 * tid + 512 * c + 1];
 #pragma unroll
-    for (int q = 0; q < CGS_ROWS; ++q) if (row0 + q < n) acc[q] += St[(size_t)(row0 + q) * n + n - 1] * s_p[n - 1];
+    for (int q = 0; q < ROWS; ++q) acc[q] += sv[q][c].x * p0 + sv[q][c].y * p1;
   }
 #pragma unroll
-  for (int q = 0; q < CGS_ROWS; ++q) {
+  for (int q = 0; q < ROWS; ++q) {
     const double t = wave_sum(acc[q]);
     if (lane == 0) s_row[q][w] = t;
   }
   __syncthreads();
-  if (tid < CGS_ROWS && row0 + tid < n) out[2 * n + row0 + tid] = (s_row[tid][0] + s_row[tid][1]) + (s_row[tid][2] + s_row[tid][3]);
+  if (tid < ROWS && row0 + tid < n) out[2 * n + row0 + tid] = (s_row[tid][0] + s_row[tid][1]) + (s_row[tid][2] + s_row[tid][3]);
 }
 
 // x~ = S~^-1 rhs~ by CG; returns 0 converged / 1 not converged or broken (caller falls back to the factorisation)
 static int cgs_solve(sfm_ctx* h, int n, const double* St, const double* rhs_t, double* x_t, double* vec, double* scal,
                      double rtol, int* iters_out, int* status) {
-  const int per_xcd_wg = (int)cdiv(cdiv(n, 8), CGS_ROWS);
+  // (column chunks per thread, rows per workgroup): 128 registers of prefetched matrix per thread in the two larger shapes
+  const int shape = n <= 1024 ? 0 : (n <= 2048 ? 1 : 2);
+  const int rows = shape == 2 ? 4 : 8;
+  const int per_xcd_wg = (int)cdiv(cdiv(n, 8), rows);
   const unsigned grid = 8u * (unsigned)per_xcd_wg;
   hipLaunchKernelGGL(k_cgs_init, dim3(1), dim3(256), 0, h->stream, n, rhs_t, x_t, vec, vec + n, scal);
   int it = 0;
   *status = 1;
   const double rtol2 = rtol * rtol;
+  int batch = 13;                                                  // launch 0 only multiplies: first look after 12 iterations
   while (it <= CGS_MAX_ITER) {
-    const int batch = it == 0 ? 17 : 8;                           // first look after 16 iterations, then every 8
     for (int b = 0; b < batch; ++b, ++it)
-      hipLaunchKernelGGL(k_cgs_iter, dim3(grid), dim3(256), 0, h->stream, n, it, rtol2, St, vec, x_t, scal);
+      if (shape == 0) hipLaunchKernelGGL((k_cgs_iter<2, 8>), dim3(grid), dim3(256), 0, h->stream, n, it, rtol2, St, vec, x_t, scal);
+      else if (shape == 1) hipLaunchKernelGGL((k_cgs_iter<4, 8>), dim3(grid), dim3(256), 0, h->stream, n, it, rtol2, St, vec, x_t, scal);
+      else hipLaunchKernelGGL((k_cgs_iter<8, 4>), dim3(grid), dim3(256), 0, h->stream, n, it, rtol2, St, vec, x_t, scal);
     SFM_HIP(h, hipMemcpyAsync(h->pinned, scal, 8 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
     SFM_HIP(h, hipStreamSynchronize(h->stream));
     if (h->pinned[CGS_FAIL] != 0.0) break;
-    if (h->pinned[CGS_DONE] != 0.0 || h->pinned[CGS_RR] <= rtol2 * h->pinned[CGS_RR0]) { *status = 0; break; }
+    const double rr = h->pinned[CGS_RR], rr0 = h->pinned[CGS_RR0];
+    if (h->pinned[CGS_DONE] != 0.0 || rr <= rtol2 * rr0) { *status = 0; break; }
+    // next look where the residual should be small enough, from the average rate so far (CG on these systems converges
+    // close to linearly): every look costs a stream synchronisation, every launch past convergence ~4 us
+    const double done_its = h->pinned[CGS_ITER] > 1.0 ? h->pinned[CGS_ITER] : 1.0;
+    const double rate = std::log(rr / rr0) / done_its;               // < 0 when converging
+    batch = 8;
+    if (rate < -1e-3 && rr > 0.0) {
+      const double need = std::log(rtol2 * rr0 / rr) / rate;
+      batch = need < 2.0 ? 2 : (need > 32.0 ? 32 : (int)need + 2);
+    }
   }
   *iters_out += (int)h->pinned[CGS_ITER];
   SFM_LAUNCH_CHECK(h, "cgs_solve");
