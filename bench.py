@@ -80,6 +80,9 @@ def main():
                 sk.bind(("127.0.0.1", 0))
                 os.environ.setdefault("MASTER_PORT", str(sk.getsockname()[1]))
             os.environ.update(RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+        # stdout carries ONE JSON line: keep RCCL's version banner (printed to stdout at NCCL_DEBUG=VERSION) out of it
+        if os.environ.get("NCCL_DEBUG", "").upper() == "VERSION":
+            os.environ["NCCL_DEBUG"] = "WARN"
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         comm = DistComm()
         comm.force = True

@@ -1124,6 +1124,39 @@ static int pack_S(sfm_handle h, sfm_ba_problem p, int unpack_dir, const char* wh
 extern "C" int sfm_ba_pack_system(sfm_handle h, sfm_ba_problem p) { return pack_S(h, p, 0, "sfm_ba_pack_system"); }
 extern "C" int sfm_ba_unpack_system(sfm_handle h, sfm_ba_problem p) { return pack_S(h, p, 1, "sfm_ba_unpack_system"); }
 
+// In-register Cholesky of a small SPD block and the inverse of its factor (one thread per block; D <= 10):
+// L (lower part valid on entry) <- chol(L), X <- L^-1 (lower, zeros above).  Returns false on a non-positive pivot.
+template <int D>
+__device__ __forceinline__ bool small_chol_inverse(double (&L)[D][D], double (&X)[D][D]) {
+  bool ok = true;
+#pragma unroll
+  for (int j = 0; j < D; ++j) {
+    double sum = L[j][j];
+#pragma unroll
+    for (int k = 0; k < j; ++k) sum -= L[j][k] * L[j][k];
+    if (!(sum > 0.0)) { ok = false; sum = 1.0; }
+    const double l = sqrt(sum);
+    L[j][j] = l;
+#pragma unroll
+    for (int i = j + 1; i < D; ++i) {
+      double t = L[i][j];
+#pragma unroll
+      for (int k = 0; k < j; ++k) t -= L[i][k] * L[j][k];
+      L[i][j] = t / l;
+    }
+  }
+#pragma unroll
+  for (int t = 0; t < D; ++t)
+#pragma unroll
+    for (int r = 0; r < D; ++r) {
+      double sum = (r == t) ? 1.0 : 0.0;
+#pragma unroll
+      for (int k = 0; k < r; ++k) sum -= (k >= t ? L[r][k] * X[k][t] : 0.0);
+      X[r][t] = (r >= t) ? sum / L[r][r] : 0.0;
+    }
+  return ok;
+}
+
 // (defined with the implicit-Schur PCG further down)
 __global__ void k_dot(int n, const double* __restrict__ a, const double* __restrict__ b, double* __restrict__ out);
 __global__ void k_finish_solve_pcg(int n, const double* __restrict__ pc, const double* __restrict__ red_q, int want_q,
@@ -1161,32 +1194,7 @@ __global__ void k_diag_einv(int C, const double* __restrict__ S, int n, double a
   for (int i = 0; i < D; ++i)
 #pragma unroll
     for (int j = 0; j < D; ++j) L[i][j] = (j <= i) ? blk[(size_t)i * n + j] + (i == j ? alpha : 0.0) : 0.0;
-  bool bad = false;
-#pragma unroll
-  for (int j = 0; j < D; ++j) {
-    double sum = L[j][j];
-#pragma unroll
-    for (int k = 0; k < j; ++k) sum -= L[j][k] * L[j][k];
-    if (!(sum > 0.0)) { bad = true; sum = 1.0; }
-    const double l = sqrt(sum);
-    L[j][j] = l;
-#pragma unroll
-    for (int i = j + 1; i < D; ++i) {
-      double t = L[i][j];
-#pragma unroll
-      for (int k = 0; k < j; ++k) t -= L[i][k] * L[j][k];
-      L[i][j] = t / l;
-    }
-  }
-#pragma unroll
-  for (int t = 0; t < D; ++t)
-#pragma unroll
-    for (int r = 0; r < D; ++r) {
-      double sum = (r == t) ? 1.0 : 0.0;
-#pragma unroll
-      for (int k = 0; k < r; ++k) sum -= (k >= t ? L[r][k] * X[k][t] : 0.0);
-      X[r][t] = (r >= t) ? sum / L[r][r] : 0.0;
-    }
+  const bool bad = !small_chol_inverse<D>(L, X);
 #pragma unroll
   for (int i = 0; i < D; ++i)
 #pragma unroll
@@ -1553,33 +1561,7 @@ __global__ void k_precond_invert(int C, const double* __restrict__ M, double alp
   for (int i = 0; i < D; ++i)
 #pragma unroll
     for (int j = 0; j < D; ++j) L[i][j] = 0.5 * (M[(size_t)c * D * D + i * D + j] + M[(size_t)c * D * D + j * D + i]) + (i == j ? alpha : 0.0);
-  bool bad = false;
-#pragma unroll
-  for (int j = 0; j < D; ++j) {
-    double s = L[j][j];
-#pragma unroll
-    for (int k = 0; k < j; ++k) s -= L[j][k] * L[j][k];
-    if (!(s > 0.0)) { bad = true; s = 1.0; }
-    const double l = sqrt(s);
-    L[j][j] = l;
-#pragma unroll
-    for (int i = j + 1; i < D; ++i) {
-      double t = L[i][j];
-#pragma unroll
-      for (int k = 0; k < j; ++k) t -= L[i][k] * L[j][k];
-      L[i][j] = t / l;
-    }
-  }
-  // X = L^-1 (lower), then Minv = X^T X
-#pragma unroll
-  for (int t = 0; t < D; ++t)
-#pragma unroll
-    for (int r = 0; r < D; ++r) {
-      double sum = (r == t) ? 1.0 : 0.0;
-#pragma unroll
-      for (int k = 0; k < r; ++k) sum -= (k >= t ? L[r][k] * X[k][t] : 0.0);
-      X[r][t] = (r >= t) ? sum / L[r][r] : 0.0;
-    }
+  const bool bad = !small_chol_inverse<D>(L, X);      // X = L^-1, then Minv = X^T X
 #pragma unroll
   for (int i = 0; i < D; ++i)
 #pragma unroll
