@@ -9,10 +9,12 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/prof_$ROUND
 rm -rf "$OUT"; mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-BA="--no-cpu-baseline --no-matcher --no-d6 --no-mixed --no-pcg --no-dropin --no-driver-rows"
+BA="--no-cpu-baseline --no-matcher --no-d6 --no-mixed --no-pcg --no-dropin --no-driver-rows --no-alt-camera-solver"
 echo "[1/7] bench line (defaults)";           python3 $R/bench.py > $OUT/bench.json 2> $OUT/bench.err || exit 1
 echo "[2/7] kernel trace + stats (BA + matcher)"
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt -- python3 $R/bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-d6 --no-mixed --no-pcg --no-dropin --no-driver-rows > $OUT/kt.log 2>&1 || exit 1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt -- python3 $R/bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-d6 --no-mixed --no-pcg --no-dropin --no-driver-rows --no-alt-camera-solver > $OUT/kt.log 2>&1 || exit 1
+echo "[2b/7] kernel trace + stats with the factorisation forced"
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/ktc -- python3 $R/bench.py --steps 4 --warmup 2 --camera-solver cholesky $BA > $OUT/ktc.log 2>&1 || exit 1
 echo "[3/7] PMC FETCH_SIZE";  rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/fetch -- python3 $R/bench.py --steps 2 --warmup 1 $BA > $OUT/fetch.log 2>&1 || exit 1
 echo "[4/7] PMC WRITE_SIZE";  rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/write -- python3 $R/bench.py --steps 2 --warmup 1 $BA > $OUT/write.log 2>&1 || exit 1
 echo "[5/7] matcher SQ counters (two passes)"
@@ -22,7 +24,7 @@ echo "[6/7] cfg3 bench line (50 cams / 20k pts / 200k obs)"
 python3 $R/bench.py --cams 50 --pts 20000 --no-matcher --no-driver-rows --no-dropin > $OUT/bench_cfg3.json 2> $OUT/bench_cfg3.err || exit 1
 echo "[7/7] cfg5 bench line (1000 cams / 500k pts / 5M obs) + kernel stats"
 python3 $R/bench.py --cams 1000 --pts 500000 --steps 3 --warmup 1 --no-matcher --no-driver-rows --no-dropin --no-d6 --no-cpu-baseline > $OUT/bench_cfg5.json 2> $OUT/bench_cfg5.err || exit 1
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt5 -- python3 $R/bench.py --cams 1000 --pts 500000 --steps 2 --warmup 1 --no-matcher --no-driver-rows --no-dropin --no-d6 --no-mixed --no-pcg --no-cpu-baseline > $OUT/kt5.log 2>&1 || exit 1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt5 -- python3 $R/bench.py --cams 1000 --pts 500000 --steps 2 --warmup 1 --no-matcher --no-driver-rows --no-dropin --no-d6 --no-mixed --no-pcg --no-cpu-baseline --no-alt-camera-solver > $OUT/kt5.log 2>&1 || exit 1
 # keep only what the summariser reads (the raw traces are large)
 find $OUT -name "*kernel_trace.csv" -size +20M -delete
 du -sh $OUT

@@ -38,6 +38,7 @@ for a, b in (("bench.json", f"{rnd}_bench.json"), ("bench_cfg3.json", f"{rnd}_be
     if os.path.exists(os.path.join(src, a)):
         shutil.copy(os.path.join(src, a), os.path.join(dst, b))
 copy_stats("kt", f"{rnd}_kernel_stats.csv")
+copy_stats("ktc", f"{rnd}_kernel_stats_cholesky.csv")
 copy_stats("kt5", f"{rnd}_kernel_stats_cfg5.csv")
 
 fe, wr = counters(os.path.join(src, "fetch"), {"FETCH_SIZE"}), counters(os.path.join(src, "write"), {"WRITE_SIZE"})
