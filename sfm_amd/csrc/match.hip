@@ -61,18 +61,28 @@ __device__ __forceinline__ void top2_insert(float d, int i, float& b1d, int& b1i
 
 // ------------------------------------------------------------------------------------ row norms (uint8)
 // out[i] = sum (v+1)^2 - sub over the row, v = (byte ^ flip) as int8.  train: flip 0x80, sub = dim;
-// query: flip 0x7F, sub = 0.
+// query: flip 0x7F, sub = 0.  dim / 16 lanes per row (16-byte loads: a row is read as one coalesced run), partial sums
+// combined by shuffles; dim is 32, 64 or 128.
 __global__ __launch_bounds__(256) void k_row_norm_u8(const uint8_t* __restrict__ x, int64_t n, int dim, int flip,
                                                      int sub, int* __restrict__ out) {
-  const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (r >= n) return;
-  const uint8_t* p = x + r * dim;
+  const int parts = dim >> 4;                                  // 2, 4 or 8 lanes per row
+  const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t r = t / parts;
+  const int part = (int)(t - r * parts);
   int s = 0;
-  for (int k = 0; k < dim; ++k) {
-    const int v = (int)(int8_t)(p[k] ^ flip) + 1;
-    s += v * v;
+  if (r < n) {
+    const uint4 v = *(const uint4*)(x + r * dim + part * 16);
+    const uint32_t wds[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+      for (int sh = 0; sh < 32; sh += 8) {
+        const int b = (int)(int8_t)(((wds[q] >> sh) & 0xFFu) ^ (uint32_t)flip) + 1;
+        s += b * b;
+      }
   }
-  out[r] = s - sub;
+  for (int o = parts >> 1; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);      // the lanes of a row are adjacent and aligned
+  if (r < n && part == 0) out[r] = s - sub;
 }
 
 // ------------------------------------------------------------------------------------ L2 / uint8 on i8 MFMA
@@ -498,8 +508,8 @@ static int match_launch(sfm_ctx* h, int metric, const void* q, int64_t nq_rows, 
   if (wg)   // segments choose their own number of splits: slots a segment does not use must read as "empty" (i = -1)
     SFM_HIP(h, hipMemsetAsync(w.part, 0xFF, (size_t)8 * n_out * 2 * sizeof(Cand), h->stream));
   if (metric == SFM_METRIC_L2_U8) {
-    hipLaunchKernelGGL(k_row_norm_u8, dim3(cdiv(nt_rows, 256)), dim3(256), 0, h->stream, t8, nt_rows, dim, 0x80, dim, w.tn);
-    hipLaunchKernelGGL(k_row_norm_u8, dim3(cdiv(nq_rows, 256)), dim3(256), 0, h->stream, q8, nq_rows, dim, 0x7F, 0, w.qn);
+    hipLaunchKernelGGL(k_row_norm_u8, dim3(cdiv(nt_rows * (dim >> 4), 256)), dim3(256), 0, h->stream, t8, nt_rows, dim, 0x80, dim, w.tn);
+    hipLaunchKernelGGL(k_row_norm_u8, dim3(cdiv(nq_rows * (dim >> 4), 256)), dim3(256), 0, h->stream, q8, nq_rows, dim, 0x7F, 0, w.qn);
     const char* qb_env = getenv("SFM_MATCH_QB");           // tuning knob (dim 128, single segment only): 4 query blocks per wave
     const bool qb4 = !wg && (dim == 128) && qb_env && qb_env[0] == '4';
     if (qb4) grid = cdiv(nq_rows, 4 * 4 * 32) * nsplit;
