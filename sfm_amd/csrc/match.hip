@@ -20,12 +20,13 @@
 #include "common.h"
 #include <cstdlib>
 #include <vector>
+#include <type_traits>
 
 typedef int v4i __attribute__((ext_vector_type(4)));
 typedef int v16i __attribute__((ext_vector_type(16)));
 
-#define KEY_SENTINEL 0x7FFFFF00
 #define D2_MAX_VALID 8323200   // 128 * 255^2
+#define SENT_TH 0x3FFFFF       // accumulator start of a padding row: 2 * SENT_TH = 8388606 > every valid d^2, key below 2^31
 
 // Correctly rounded float32 square root (what sqrtf / OpenCV's std::sqrt give on the CPU): the fp64 root
 // (correctly rounded, 53 >= 2*24+2 bits) rounded once to float32.  __fsqrt_rn is NOT correctly rounded here.
@@ -86,22 +87,73 @@ __global__ __launch_bounds__(256) void k_row_norm_u8(const uint8_t* __restrict__
 }
 
 // ------------------------------------------------------------------------------------ L2 / uint8 on i8 MFMA
-// grid.x = n_qblocks * nsplit: split = blockIdx.x % nsplit so that, with the round-robin XCD placement,
-// the workgroups streaming one train split share an XCD's L2 (speed only).  256 threads = 4 waves,
-// each wave owns QB blocks of 32 queries; the train split is streamed through LDS in chunks of 128 rows
-// (XOR-swizzled 16-byte granules: conflict-free ds_read_b128), double buffered.
-template <int KS, int QB>   // KS = dim / 32
-__global__ __launch_bounds__(256) void k_knn2_u8(const uint8_t* __restrict__ q, int64_t nq,
-                                                 const uint8_t* __restrict__ t, int64_t nt,
-                                                 const int* __restrict__ tn, const int* __restrict__ qn,
-                                                 int nsplit, int64_t rows_per_split, const MatchWG* __restrict__ wg,
-                                                 int64_t total_out, Cand* __restrict__ part) {
+// Train-side pre-pass (one launch per call): per row i the accumulator start TH_i = TN_i >> 1, the key parity bit
+// PAR_i = (TN_i & 1) << 8 and the row with its bytes flipped to int8 (x ^ 0x80), so that the distance kernel can
+// bring all three into LDS with direct global->LDS loads (no registers, no ds_write).  Slot nt of every array is
+// the padding row: zero bytes, TH = SENT_TH, PAR = 0.
+__global__ __launch_bounds__(256) void k_train_prep_u8(const uint8_t* __restrict__ x, int64_t n, int dim,
+                                                       uint8_t* __restrict__ xf, int* __restrict__ th, int* __restrict__ par) {
+  const int parts = dim >> 4;
+  const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t r = t / parts;
+  const int part = (int)(t - r * parts);
+  int s = 0;
+  if (r < n) {
+    uint4 v = *(const uint4*)(x + r * dim + part * 16);
+    v.x ^= 0x80808080u; v.y ^= 0x80808080u; v.z ^= 0x80808080u; v.w ^= 0x80808080u;
+    *(uint4*)(xf + r * dim + part * 16) = v;
+    const uint32_t wds[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+      for (int sh = 0; sh < 32; sh += 8) {
+        const int b = (int)(int8_t)((wds[q] >> sh) & 0xFFu) + 1;
+        s += b * b;
+      }
+  } else if (r == n) {
+    *(uint4*)(xf + r * dim + part * 16) = make_uint4(0u, 0u, 0u, 0u);
+  }
+  for (int o = parts >> 1; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);      // the lanes of a row are adjacent and aligned
+  if (part == 0) {
+    if (r < n) { const int tn = s - dim; th[r] = tn >> 1; par[r] = (tn & 1) << 8; }
+    else if (r == n) { th[r] = SENT_TH; par[r] = 0; }
+  }
+}
+
+// loop with a compile-time index (arrays indexed by it stay in registers whatever the unroller decides)
+template <int I, int N, class F> __device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (I < N) { f(std::integral_constant<int, I>{}); static_for<I + 1, N>(f); }
+}
+typedef __attribute__((address_space(1))) const void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+// grid.x = n_qblocks * nsplit: split = blockIdx.x % nsplit, the workgroups of one query block run side by side.
+// 256 threads = 4 waves, each wave owns QB blocks of 32 queries; the train split is streamed through LDS in chunks of 128
+// rows (XOR-swizzled 16-byte granules: conflict-free ds_read_b128), double buffered through registers: the loads of chunk
+// ch + 1 are issued before chunk ch is worked on and written to LDS after it.  (Direct global->LDS loads into a ring of
+// three buffers, two chunks in flight, measured 8-13 % slower here: ~100 cycles of issue per 1 KiB piece and wave.)
+//
+// Candidate filter (FILTER): the accumulator starts at TH_i = TN_i >> 1, so that after the MFMAs
+// 2 acc + parity = d^2 - QN_j, and a candidate can only matter if acc < (U2 - QN_j) / 2 + 1, U2 = an upper bound of
+// the query's final second-best d^2: the second-best so far over both half-waves AND over the other train splits of
+// the same queries, refreshed every 256 train rows.  A 32 x 32 tile whose 16 x 64 accumulators all fail that test
+// (10 min operations + 1 compare per lane instead of 48 ranking operations) is skipped, and in a tile that is not, only
+// the groups of four rows that hold a candidate are ranked.  Skipping is exact, not approximate: the test keeps every
+// candidate with d^2 <= U2, and ties are still resolved on (d^2, index) by the ranking and the merge.
+#ifndef KNN_WAVES
+#define KNN_WAVES 2
+#endif
+template <int KS, int QB, bool FILTER>   // KS = dim / 32
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(KNN_WAVES, KNN_WAVES))) void k_knn2_u8(
+    const uint8_t* __restrict__ q, int64_t nq, const uint8_t* __restrict__ tf, int64_t nt,
+    const int* __restrict__ th_g, const int* __restrict__ par_g, const int* __restrict__ qn,
+    int nsplit, int64_t rows_per_split, const MatchWG* __restrict__ wg, int64_t total_out, Cand* __restrict__ part, int* u2g) {
   constexpr int DIM = KS * 32;
   constexpr int GPR = DIM / 16;                 // 16-byte granules per row
-  constexpr int CHUNK = 128;                   // rows per LDS chunk (2 x 16 KiB at dim 128)
+  constexpr int CHUNK = 128;                   // rows per LDS chunk
   constexpr int GPT = CHUNK * GPR / 256;        // granules staged per thread
-  __shared__ uint4 s_t[2][CHUNK * GPR];
-  __shared__ int s_k0[2][CHUNK];
+  __shared__ uint4 s_tb[2][CHUNK * GPR];
+  __shared__ int s_thb[2][CHUNK];     // TH_i = TN_i >> 1: where the accumulator of train row i starts
+  __shared__ int s_parb[2][CHUNK];    // PAR_i = (TN_i & 1) << 8: the parity bit of the key
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, half = lane >> 5, l31 = lane & 31;
   int split;
   int64_t t_beg, t_end, q0, t_seg = 0, out_shift = 0;     // out_shift: output row = query row + out_shift
@@ -135,7 +187,6 @@ __global__ __launch_bounds__(256) void k_knn2_u8(const uint8_t* __restrict__ q, 
       bq[qb][ks] = v ^ 0x7F7F7F7F;
     }
   }
-  float g1d[QB], g2d[QB];
   int g1i[QB], g2i[QB];
   int g1k[QB], g2k[QB];   // exact integer d^2 of the running best two
 #pragma unroll
@@ -144,24 +195,23 @@ __global__ __launch_bounds__(256) void k_knn2_u8(const uint8_t* __restrict__ q, 
   const int64_t n_rows = t_end > t_beg ? (t_end - t_beg) : 0;
   const int n_chunks = (int)((n_rows + CHUNK - 1) / CHUNK);
 
+  // rows past the split read the padding row (slot nt: zero bytes, TH = SENT_TH)
   uint4 stage[GPT];
-  int stage_k0 = 0;
+  int stage_th = 0, stage_par = 0;
   auto load_chunk = [&](int ch) {
     const int64_t base = t_beg + (int64_t)ch * CHUNK;
 #pragma unroll
     for (int i = 0; i < GPT; ++i) {
       const int g = tid + 256 * i;
       const int row = g / GPR, slot = g % GPR;
-      const int64_t tr = base + row;
-      uint4 v = make_uint4(0x80808080u, 0x80808080u, 0x80808080u, 0x80808080u);   // -> 0 after the flip
-      if (tr < t_end) v = *(const uint4*)(t + tr * DIM + slot * 16);
-      stage[i] = v;
+      int64_t tr = base + row;
+      if (tr >= t_end) tr = nt;
+      stage[i] = *(const uint4*)(tf + tr * DIM + slot * 16);
     }
     if (tid < CHUNK) {
-      const int64_t tr = base + tid;
-      // low 8 bits: row inside the 256-row window (two LDS chunks) the keys are unpacked after
-      const int wrow = ((ch & 1) << 7) | tid;
-      stage_k0 = (tr < t_end) ? ((tn[tr] << 8) | wrow) : (KEY_SENTINEL | wrow);
+      int64_t tr = base + tid;
+      if (tr >= t_end) tr = nt;
+      stage_th = th_g[tr]; stage_par = par_g[tr];
     }
   };
   auto store_chunk = [&](int buf) {
@@ -169,78 +219,154 @@ __global__ __launch_bounds__(256) void k_knn2_u8(const uint8_t* __restrict__ q, 
     for (int i = 0; i < GPT; ++i) {
       const int g = tid + 256 * i;
       const int row = g / GPR, slot = g % GPR;
-      const int sw = (slot ^ ((row >> 1) & (GPR - 1)));
-      uint4 v = stage[i];
-      v.x ^= 0x80808080u; v.y ^= 0x80808080u; v.z ^= 0x80808080u; v.w ^= 0x80808080u;
-      s_t[buf][row * GPR + sw] = v;
+      s_tb[buf][row * GPR + (slot ^ ((row >> 1) & (GPR - 1)))] = stage[i];
     }
-    if (tid < CHUNK) s_k0[buf][tid] = stage_k0;
+    if (tid < CHUNK) { s_thb[buf][tid] = stage_th; s_parb[buf][tid] = stage_par; }
   };
 
   // two independent (best, second) key pairs per query block - even / odd accumulator registers - halve the
   // serial min/med3 dependency chain; they are merged when the 256-row window is flushed
   int m1[QB][2], m2[QB][2];
+  int thr[QB];                       // FILTER: a candidate matters only if its accumulator is below this
+  int u2_seen[QB], u2_sent[QB];      // FILTER: what the other splits reported one window ago / what this one has reported
+#pragma unroll
+  for (int qb = 0; qb < QB; ++qb) {
+    thr[qb] = (q0 + qb * 32 + l31 < nq) ? 0x7FFFFFFF : (int)0x80000000;
+    u2_seen[qb] = u2_sent[qb] = 0x7FFFFFFF;
+  }
   if (n_chunks > 0) { load_chunk(0); store_chunk(0); }
   __syncthreads();
   for (int ch = 0; ch < n_chunks; ++ch) {
     const int buf = ch & 1;
+    const uint4* s_t = s_tb[buf];
+    const int* s_th = s_thb[buf];
+    const int* s_par = s_parb[buf];
     if (ch + 1 < n_chunks) load_chunk(ch + 1);
     if ((ch & 1) == 0) {
 #pragma unroll
       for (int qb = 0; qb < QB; ++qb) { m1[qb][0] = m1[qb][1] = 0x7FFFFFFF; m2[qb][0] = m2[qb][1] = 0x7FFFFFFF; }
     }
-#pragma unroll 2
-    for (int tile = 0; tile < CHUNK / 32; ++tile) {
+    const int wbase = ((ch & 1) << 7) | (4 * half);      // row inside the 256-row window of register 0 of tile 0
+    // Software pipeline over the (tile, query block) steps of the chunk: the matrix unit works on step s while the vector
+    // unit ranks the accumulators of step s - 1 in the gaps between its MFMAs, and the LDS operands of the next tile are
+    // fetched a tile ahead into a second register set.
+    constexpr int TILES = CHUNK / 32, STEPS = TILES * QB;
+    // with four query blocks a tile is 16 MFMAs long: one operand set, refilled behind the tile's last chain (the other
+    // wave of the SIMD covers the LDS round trip), leaves the registers to the query fragments
+    constexpr int SETS = (QB >= 4 || KNN_WAVES >= 3) ? 1 : 2;
+    v4i at[SETS][KS];
+    v16i th[SETS];       // accumulator start values of the 16 train rows a lane's registers hold: rows (r&3) + 8 (r>>2) + 4 half
+    int4 kp[4];          // parity bits of the rows of the tile being ranked (one set: fetched right after the previous tile's last ranking)
+    v16i acc[2];
+    auto load_ops = [&](int tile, int set) {
       const int row = tile * 32 + l31;
-      v4i at[KS];
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks) {
         const int slot = ks * 2 + half;
         const int sw = (slot ^ ((row >> 1) & (GPR - 1)));
-        const uint4 v = s_t[buf][row * GPR + sw];
-        at[ks] = (v4i){(int)v.x, (int)v.y, (int)v.z, (int)v.w};
+        const uint4 v = s_t[row * GPR + sw];
+        at[set][ks] = (v4i){(int)v.x, (int)v.y, (int)v.z, (int)v.w};
       }
-      // K0 of the 16 train rows this lane's accumulator registers hold: rows (r&3) + 8 (r>>2) + 4 half
-      int k0[16];
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
-        const int4 kk = *(const int4*)&s_k0[buf][tile * 32 + 8 * g + 4 * half];
-        k0[4 * g] = kk.x; k0[4 * g + 1] = kk.y; k0[4 * g + 2] = kk.z; k0[4 * g + 3] = kk.w;
+        const int4 kk = *(const int4*)&s_th[tile * 32 + 8 * g + 4 * half];
+        th[set][4 * g] = kk.x; th[set][4 * g + 1] = kk.y; th[set][4 * g + 2] = kk.z; th[set][4 * g + 3] = kk.w;
       }
+    };
+    auto load_kp = [&](int tile) {
 #pragma unroll
-      for (int qb = 0; qb < QB; ++qb) {
-        v16i acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+      for (int g = 0; g < 4; ++g) kp[g] = *(const int4*)&s_par[tile * 32 + 8 * g + 4 * half];
+    };
+    int gm[4];                                            // FILTER: smallest accumulator of each group of four rows
+    auto rank_group_min = [&](const v16i& a, int g) {
+      gm[g] = min(min(min(a[4 * g], a[4 * g + 1]), a[4 * g + 2]), a[4 * g + 3]);
+    };
+    auto rank_finish = [&](const v16i& a, int tile, int qb) {
+      if (FILTER) {
+        const int mn = min(min(min(gm[0], gm[1]), gm[2]), gm[3]);
+        if (__builtin_amdgcn_ballot_w64(mn < thr[qb]) == 0ull) return;               // wave-uniform: nothing in this tile can enter a top-2
+      }
+      if (KNN_WAVES >= 3) load_kp(tile);                    // lean build: the parity bits only when a tile is ranked at all
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks) acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(at[ks], bq[qb][ks], acc, 0, 0, 0);
+      for (int g = 0; g < 4; ++g) {
+        // past the first windows a tile that is not skipped has one or two candidates: only their groups are ranked
+        if (FILTER && __builtin_amdgcn_ballot_w64(gm[g] < thr[qb]) == 0ull) continue;
+        const int kpr[4] = {kp[g].x, kp[g].y, kp[g].z, kp[g].w};
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int key = (acc[r] << 9) + k0[r];
+        for (int j = 0; j < 4; ++j) {
+          const int r = 4 * g + j;
+          // ((2 acc + parity) << 8) | row in window = ((d^2 - QN) << 8) | row
+          const int key = (a[r] << 9) + (kpr[j] + (wbase + tile * 32 + 8 * g + j));
           int nm2;
           asm("v_med3_i32 %0, %1, %2, %3" : "=v"(nm2) : "v"(m1[qb][r & 1]), "v"(m2[qb][r & 1]), "v"(key));
           m2[qb][r & 1] = nm2;
           m1[qb][r & 1] = min(m1[qb][r & 1], key);
         }
       }
+    };
+    load_ops(0, 0);
+    if (KNN_WAVES < 3) load_kp(0);
+#pragma unroll
+    for (int st = 0; st < STEPS; ++st) {
+      const int tile = st / QB, qb = st % QB, set = tile & (SETS - 1);
+      const v16i& prev = acc[(st - 1) & 1];
+      if (SETS == 2 && qb == 0 && tile + 1 < TILES) load_ops(tile + 1, set ^ 1);     // that set's last MFMA was issued a step ago
+      acc[st & 1] = th[set];
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        acc[st & 1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(at[set][ks], bq[qb][ks], acc[st & 1], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (FILTER && st > 0) {                                          // KS gaps for the four group minima
+          for (int g = ks * 4 / KS; g < (ks + 1) * 4 / KS; ++g) rank_group_min(prev, g);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+      if (SETS == 1 && qb == QB - 1 && tile + 1 < TILES) load_ops(tile + 1, 0);      // behind the last chain that reads the set
+      if (st > 0) rank_finish(prev, (st - 1) / QB, (st - 1) % QB);
+      if (KNN_WAVES < 3 && qb == 0 && tile > 0) load_kp(tile);          // after the last ranking that read the previous tile's
     }
+#pragma unroll
+    for (int g = 0; g < 4; ++g) rank_group_min(acc[(STEPS - 1) & 1], g);
+    rank_finish(acc[(STEPS - 1) & 1], TILES - 1, QB - 1);
     // every second chunk (and at the end): unpack the window's best two and merge into the running pair
     // (later windows = higher indices, so strict '<' keeps the lower index on equal d^2)
     const int cbase = (int)(t_beg - t_seg + (int64_t)(ch & ~1) * CHUNK);      // train index inside the segment
     if ((ch & 1) == 1 || ch + 1 == n_chunks) {
-#pragma unroll
-    for (int qb = 0; qb < QB; ++qb) {
+    static_for<0, QB>([&](auto qbc) __attribute__((always_inline)) {
+      constexpr int qb = decltype(qbc)::value;
       // keys carry the row index, so they are totally ordered: best two of the four
       const int lo = min(m1[qb][0], m1[qb][1]), hi = max(m1[qb][0], m1[qb][1]);
       const int second = min(hi, min(m2[qb][0], m2[qb][1]));
-#pragma unroll
-      for (int s = 0; s < 2; ++s) {
-        const int m = s == 0 ? lo : second;
-        if ((m | 0xFF) == (KEY_SENTINEL | 0xFF) || m == 0x7FFFFFFF) continue;
+      static_for<0, 2>([&](auto sc) __attribute__((always_inline)) {
+        const int m = decltype(sc)::value == 0 ? lo : second;
+        const bool ok = (m >> 8) < 2 * SENT_TH;            // not a padding row or an empty slot
         const int d2 = (m >> 8) + qnv[qb];
         const int idx = cbase + (m & 0xFF);
-        if (d2 < g1k[qb]) { g2k[qb] = g1k[qb]; g2i[qb] = g1i[qb]; g1k[qb] = d2; g1i[qb] = idx; }
-        else if (d2 < g2k[qb]) { g2k[qb] = d2; g2i[qb] = idx; }
+        // selects, not branches: hipcc merges the stores of an if / else-if through a selected ADDRESS, which puts the
+        // four running values in scratch memory - and every scratch access drains the chunk prefetch (vmcnt)
+        const bool c1 = ok && d2 < g1k[qb], c2 = ok && !c1 && d2 < g2k[qb];
+        g2k[qb] = c1 ? g1k[qb] : (c2 ? d2 : g2k[qb]);
+        g2i[qb] = c1 ? g1i[qb] : (c2 ? idx : g2i[qb]);
+        g1k[qb] = c1 ? d2 : g1k[qb];
+        g1i[qb] = c1 ? idx : g1i[qb];
+      });
+      if (FILTER) {
+        // second-best d^2 of the query over BOTH half-waves (they hold disjoint train rows of the same query) ...
+        const int o1 = __shfl_xor(g1k[qb], 32, 64), o2 = __shfl_xor(g2k[qb], 32, 64);
+        int u2 = min(min(g2k[qb], o2), max(g1k[qb], o1));
+        // ... and over the other train splits of the same queries, which run side by side on other XCDs: every
+        // split posts its bound with an atomic minimum and picks up the combined one a window later (the returned value
+        // is not waited for here).  Any stale or missing value only leaves the threshold looser: a bound is the
+        // second-best d^2 over SOME train rows, so no row of the final top-2 lies above it.
+        u2 = min(u2, u2_seen[qb]);
+        if (half == 0 && thr[qb] != (int)0x80000000 && u2 < u2_sent[qb]) {
+          u2_seen[qb] = atomicMin(u2g + (q0 + qb * 32 + l31 + out_shift), u2);
+          u2_sent[qb] = u2;
+        }
+        u2 = min(u2, __shfl_xor(u2, 32, 64));
+        if (thr[qb] != (int)0x80000000) thr[qb] = (u2 == 0x7FFFFFFF) ? 0x7FFFFFFF : ((u2 - qnv[qb]) >> 1) + 1;
       }
-    }
+    });
     }
     if (ch + 1 < n_chunks) store_chunk(buf ^ 1);
     __syncthreads();
@@ -250,10 +376,9 @@ __global__ __launch_bounds__(256) void k_knn2_u8(const uint8_t* __restrict__ q, 
   for (int qb = 0; qb < QB; ++qb) {
     const int o1k = __shfl_xor(g1k[qb], 32, 64), o1i = __shfl_xor(g1i[qb], 32, 64);
     const int o2k = __shfl_xor(g2k[qb], 32, 64), o2i = __shfl_xor(g2i[qb], 32, 64);
-    g1d[qb] = (float)g1k[qb]; g2d[qb] = (float)g2k[qb];      // exact: d^2 < 2^24
     float b1d = 3.0e38f, b2d = 3.0e38f; int b1i = -1, b2i = -1;
-    top2_insert(g1d[qb], g1i[qb], b1d, b1i, b2d, b2i);
-    top2_insert(g2d[qb], g2i[qb], b1d, b1i, b2d, b2i);
+    top2_insert((float)g1k[qb], g1i[qb], b1d, b1i, b2d, b2i);      // exact: d^2 < 2^24
+    top2_insert((float)g2k[qb], g2i[qb], b1d, b1i, b2d, b2i);
     top2_insert((float)o1k, o1i, b1d, b1i, b2d, b2i);
     top2_insert((float)o2k, o2i, b1d, b1i, b2d, b2i);
     const int64_t qi = q0 + qb * 32 + l31;
@@ -466,24 +591,44 @@ __global__ __launch_bounds__(256) void k_f32_to_u8(const float* __restrict__ src
 }
 
 // ------------------------------------------------------------------------------------ host
-static int pick_nsplit(int64_t nt) {
-  // enough workgroups to fill 256 CUs a few times over, but splits of at least 512 train rows
-  int ns = 8;
-  while (ns > 1 && nt / ns < 512) ns >>= 1;
-  return ns;
+static int pick_nsplit(int64_t nt, int64_t n_qblocks) {
+  // Splits of the train set buy parallelism (workgroups = query blocks x splits; the splits of one query block run side
+  // by side and share their candidate threshold, so they do not loosen the filter).  The distance kernel holds two
+  // workgroups per CU: take the split count (<= 8, splits of at least 512 rows) whose LAST round of 512 workgroups is
+  // fullest - at 50k x 50k, 196 query blocks: 5 splits = 1.9 rounds against 8 = 3.06, 10 % of the launch.
+  // SFM_MATCH_NSPLIT overrides (tuning).
+  const char* env = getenv("SFM_MATCH_NSPLIT");
+  int best = 1;
+  if (env) {
+    best = atoi(env);
+    if (best > 8) best = 8;
+    if (best < 1) best = 1;
+  } else {
+    double best_cost = 1e30;
+    for (int ns = 1; ns <= 8; ++ns) {
+      const int64_t wgs = n_qblocks * ns, rounds = (wgs + 511) / 512;
+      const double cost = (double)rounds / ns;             // time ~ rounds x rows per split
+      if (cost < best_cost * 0.98) { best_cost = cost; best = ns; }
+    }
+  }
+  while (best > 1 && nt / best < 512) --best;
+  return best;
 }
 
 // workspace carve (bytes): per-split candidates | train norms | query norms | ratio scratch | re-rank list + counter |
 // (batched only) workgroup records + segment table
 struct MatchWs {
-  Cand* part; int* tn; int* qn; int* fix_list; int* fix_cnt; char* plan; int64_t total;
+  Cand* part; uint8_t* tf; int* th; int* par; int* qn; int* u2; int* fix_list; int* fix_cnt; char* plan; int64_t total;
 };
 static MatchWs match_ws_carve(char* ws, int64_t n_out, int64_t nt_rows, int64_t nq_rows, int64_t plan_bytes) {
   MatchWs w;
   int64_t off = 0;
   w.part = (Cand*)(ws + off); off += align_up(8 * n_out * 2 * (int64_t)sizeof(Cand), 256);   // nsplit <= 8
-  w.tn = (int*)(ws + off); off += align_up(nt_rows * 4, 256);
+  w.tf = (uint8_t*)(ws + off); off += align_up((nt_rows + 1) * 128, 256);                       // int8 copy of the train rows + padding row (dim <= 128)
+  w.th = (int*)(ws + off); off += align_up((nt_rows + 1) * 4, 256);
+  w.par = (int*)(ws + off); off += align_up((nt_rows + 1) * 4, 256);
   w.qn = (int*)(ws + off); off += align_up(nq_rows * 4, 256);
+  w.u2 = (int*)(ws + off); off += align_up(n_out * 4, 256);                                     // shared candidate thresholds (k_knn2_u8)
   off += align_up(((n_out + 255) / 256) * 8 + 64, 256);                                        // sfm_match_ratio's scratch may alias here
   w.fix_list = (int*)(ws + off); off += align_up(n_out * 4, 256);
   w.fix_cnt = (int*)(ws + off); off += 256;
@@ -501,27 +646,30 @@ extern "C" int sfm_match_workspace_bytes(int metric, int64_t nq, int64_t nt, int
 
 // The distance + top-2 stage for one segment (wg == nullptr) or a planned batch.  n_out = output rows.
 static int match_launch(sfm_ctx* h, int metric, const void* q, int64_t nq_rows, const void* t, int64_t nt_rows, int dim,
-                        int nsplit, int64_t rps, const MatchWG* wg, unsigned grid, int64_t n_out, MatchSegs segs,
+                        int nsplit, int64_t rps, int64_t qpw /* queries per workgroup */, int64_t filter_rows /* train rows of the longest segment */,
+                        const MatchWG* wg, unsigned grid, int64_t n_out, MatchSegs segs,
                         const MatchWs& w, int32_t* idx1, int32_t* idx2, float* d1, float* d2) {
   const uint8_t* q8 = (const uint8_t*)q; const uint8_t* t8 = (const uint8_t*)t;
   const uint32_t* qq = (const uint32_t*)q; const uint32_t* tt = (const uint32_t*)t;
   if (wg)   // segments choose their own number of splits: slots a segment does not use must read as "empty" (i = -1)
     SFM_HIP(h, hipMemsetAsync(w.part, 0xFF, (size_t)8 * n_out * 2 * sizeof(Cand), h->stream));
   if (metric == SFM_METRIC_L2_U8) {
-    hipLaunchKernelGGL(k_row_norm_u8, dim3(cdiv(nt_rows * (dim >> 4), 256)), dim3(256), 0, h->stream, t8, nt_rows, dim, 0x80, dim, w.tn);
+    hipLaunchKernelGGL(k_train_prep_u8, dim3(cdiv((nt_rows + 1) * (dim >> 4), 256)), dim3(256), 0, h->stream, t8, nt_rows, dim, w.tf, w.th, w.par);
     hipLaunchKernelGGL(k_row_norm_u8, dim3(cdiv(nq_rows * (dim >> 4), 256)), dim3(256), 0, h->stream, q8, nq_rows, dim, 0x7F, 0, w.qn);
-    const char* qb_env = getenv("SFM_MATCH_QB");           // tuning knob (dim 128, single segment only): 4 query blocks per wave
-    const bool qb4 = !wg && (dim == 128) && qb_env && qb_env[0] == '4';
-    if (qb4) grid = cdiv(nq_rows, 4 * 4 * 32) * nsplit;
+    const bool qb4 = qpw == 512;
+    // the candidate filter pays once the queries see a few thousand train rows (see k_knn2_u8); below that it is 10
+    // operations per tile for nothing
+    const char* f_env = getenv("SFM_MATCH_FILTER");        // test / tuning knob: "0" off, "1" on
+    const bool filter = f_env ? f_env[0] == '1' : filter_rows >= 2048;
+    if (filter) SFM_HIP(h, hipMemsetAsync(w.u2, 0x7F, (size_t)n_out * sizeof(int), h->stream));      // "no bound yet"
     sfm_prof_begin(h, SFM_PROF_KNN);
-    if (qb4)
-      hipLaunchKernelGGL((k_knn2_u8<4, 4>), dim3(grid), dim3(256), 0, h->stream, q8, nq_rows, t8, nt_rows, w.tn, w.qn, nsplit, rps, wg, n_out, w.part);
-    else if (dim == 128)
-      hipLaunchKernelGGL((k_knn2_u8<4, 2>), dim3(grid), dim3(256), 0, h->stream, q8, nq_rows, t8, nt_rows, w.tn, w.qn, nsplit, rps, wg, n_out, w.part);
-    else if (dim == 64)
-      hipLaunchKernelGGL((k_knn2_u8<2, 2>), dim3(grid), dim3(256), 0, h->stream, q8, nq_rows, t8, nt_rows, w.tn, w.qn, nsplit, rps, wg, n_out, w.part);
-    else
-      hipLaunchKernelGGL((k_knn2_u8<1, 2>), dim3(grid), dim3(256), 0, h->stream, q8, nq_rows, t8, nt_rows, w.tn, w.qn, nsplit, rps, wg, n_out, w.part);
+#define KNN_LAUNCH(KS, QB, F) hipLaunchKernelGGL((k_knn2_u8<KS, QB, F>), dim3(grid), dim3(256), 0, h->stream, q8, nq_rows, w.tf, nt_rows, w.th, w.par, w.qn, nsplit, rps, wg, n_out, w.part, w.u2)
+    if (filter) {
+      if (qb4) KNN_LAUNCH(4, 4, true); else if (dim == 128) KNN_LAUNCH(4, 2, true); else if (dim == 64) KNN_LAUNCH(2, 2, true); else KNN_LAUNCH(1, 2, true);
+    } else {
+      if (qb4) KNN_LAUNCH(4, 4, false); else if (dim == 128) KNN_LAUNCH(4, 2, false); else if (dim == 64) KNN_LAUNCH(2, 2, false); else KNN_LAUNCH(1, 2, false);
+    }
+#undef KNN_LAUNCH
     sfm_prof_end(h, SFM_PROF_KNN);
     SFM_HIP(h, hipMemsetAsync(w.fix_cnt, 0, sizeof(int), h->stream));
     hipLaunchKernelGGL(k_merge_splits_u8, dim3(cdiv(n_out, 256)), dim3(256), 0, h->stream, n_out, wg ? 8 : nsplit, w.part, idx1, idx2,
@@ -558,9 +706,17 @@ static int match_check_metric(sfm_ctx* h, int metric, int dim, const char* what)
   }
   return SFM_OK;
 }
+// queries one workgroup of the distance kernel takes
+static int64_t match_qpw(int metric, int dim, int64_t nq, bool batched) {
+  // k_knn2_u8 with four query blocks per wave (512 queries per workgroup: half the train bytes through LDS per pair)
+  // once there are enough queries to fill the chip that way; single segment, dim 128.  SFM_MATCH_QB = 2 / 4 overrides.
+  const char* qb_env = getenv("SFM_MATCH_QB");
+  const bool qb4 = !batched && metric == SFM_METRIC_L2_U8 && dim == 128 && (qb_env ? qb_env[0] == '4' : nq >= 16384);
+  return qb4 ? 512 : 256;
+}
 // rows of train data per split and queries per workgroup of the kernel a metric uses
-static void match_tiling(int metric, int64_t nt, int* nsplit, int64_t* rps) {
-  int ns = pick_nsplit(nt);
+static void match_tiling(int metric, int64_t nq, int64_t qpw, int64_t nt, int* nsplit, int64_t* rps) {
+  int ns = pick_nsplit(nt, (nq + qpw - 1) / qpw);
   int64_t r = (nt + ns - 1) / ns;
   if (metric == SFM_METRIC_L2_U8) r = align_up(r, 128);
   *nsplit = (int)((nt + r - 1) / r);
@@ -578,23 +734,26 @@ extern "C" int sfm_match_knn2(sfm_handle h, int metric, const void* q, int64_t n
   const MatchWs w = match_ws_carve((char*)workspace, nq, nt, nq, 0);
   if (workspace_bytes < w.total) return sfm_fail(h, SFM_ERR_WORKSPACE, "sfm_match_knn2", "workspace too small");
   int nsplit; int64_t rps;
-  match_tiling(metric, nt, &nsplit, &rps);
-  const unsigned grid = cdiv(nq, 256) * nsplit;
+  const int64_t qpw = match_qpw(metric, dim, nq, false);
+  match_tiling(metric, nq, qpw, nt, &nsplit, &rps);
+  const unsigned grid = cdiv(nq, qpw) * nsplit;
   MatchSegs none = {nullptr, nullptr, nullptr, nullptr, 0};
-  return match_launch(h, metric, q, nq, t, nt, dim, nsplit, rps, nullptr, grid, nq, none, w, idx1, idx2, d1, d2);
+  return match_launch(h, metric, q, nq, t, nt, dim, nsplit, rps, qpw, nt, nullptr, grid, nq, none, w, idx1, idx2, d1, d2);
 }
 
 // ---- batched: every image pair of a preprocessing step in one launch
-static void plan_segments(int metric, int32_t n_seg, const int64_t* q_beg, const int64_t* q_end, const int64_t* t_beg,
+static void plan_segments(int metric, int dim, int32_t n_seg, const int64_t* q_beg, const int64_t* q_end, const int64_t* t_beg,
                           const int64_t* t_end, std::vector<MatchWG>* wgs, std::vector<int64_t>* out_ptr) {
   out_ptr->assign((size_t)n_seg + 1, 0);
+  int64_t all_queries = 0;                           // parallelism comes from all segments together
+  for (int s = 0; s < n_seg; ++s) all_queries += (q_end[s] - q_beg[s] + 255) / 256 * 256;
   for (int s = 0; s < n_seg; ++s) {
     const int64_t nq = q_end[s] - q_beg[s], nt = t_end[s] - t_beg[s];
     (*out_ptr)[s + 1] = (*out_ptr)[s] + nq;
     if (nq <= 0) continue;
     int nsplit; int64_t rps;
-    match_tiling(metric, nt, &nsplit, &rps);
-    for (int64_t qb = 0; qb < nq; qb += 256)
+    match_tiling(metric, all_queries, 256, nt, &nsplit, &rps);
+    for (int64_t qb = 0; qb < nq; qb += match_qpw(metric, dim, nq, true))
       for (int sp = 0; sp < nsplit; ++sp) {          // consecutive workgroups = consecutive splits: one XCD per split as in the single-pair launch
         MatchWG r;
         r.q_first = q_beg[s] + qb; r.q_end = q_end[s];
@@ -610,7 +769,8 @@ extern "C" int sfm_match_batched_workspace_bytes(int metric, int32_t n_seg, cons
                                                  int64_t nt_rows, int64_t* n_out_host, int64_t* bytes_host) {
   if (n_seg < 1 || !q_beg_host || !q_end_host || !t_beg_host || !t_end_host || !n_out_host || !bytes_host) return SFM_ERR_ARG;
   std::vector<MatchWG> wgs; std::vector<int64_t> out_ptr;
-  plan_segments(metric, n_seg, q_beg_host, q_end_host, t_beg_host, t_end_host, &wgs, &out_ptr);
+  plan_segments(metric, 32 /* the descriptor size is not known here: the smallest pieces, i.e. the longest plan */, n_seg, q_beg_host,
+                q_end_host, t_beg_host, t_end_host, &wgs, &out_ptr);
   *n_out_host = out_ptr[n_seg];
   const int64_t plan_bytes = (int64_t)wgs.size() * sizeof(MatchWG) + 4 * ((int64_t)n_seg + 1) * 8 + 256;
   *bytes_host = match_ws_carve(nullptr, out_ptr[n_seg] > 0 ? out_ptr[n_seg] : 1, nt_rows, nq_rows, plan_bytes).total;
@@ -633,7 +793,7 @@ extern "C" int sfm_match_knn2_batched(sfm_handle h, int metric, const void* q, i
       return sfm_fail(h, SFM_ERR_ARG, "sfm_match_knn2_batched", "a segment with queries needs at least 2 train rows");
   }
   std::vector<MatchWG> wgs; std::vector<int64_t> out_ptr;
-  plan_segments(metric, n_seg, q_beg_host, q_end_host, t_beg_host, t_end_host, &wgs, &out_ptr);
+  plan_segments(metric, dim, n_seg, q_beg_host, q_end_host, t_beg_host, t_end_host, &wgs, &out_ptr);
   const int64_t n_out = out_ptr[n_seg];
   if (n_out < 1) return sfm_fail(h, SFM_ERR_ARG, "sfm_match_knn2_batched", "no query rows");
   const int64_t wg_bytes = (int64_t)wgs.size() * sizeof(MatchWG), seg_bytes = ((int64_t)n_seg + 1) * 8;
@@ -651,7 +811,9 @@ extern "C" int sfm_match_knn2_batched(sfm_handle h, int metric, const void* q, i
     SFM_HIP(h, hipMemcpyAsync(out_ptr_device, out_ptr.data(), (size_t)seg_bytes, hipMemcpyHostToDevice, h->stream));
   SFM_HIP(h, hipStreamSynchronize(h->stream));          // the host vectors are pageable: the copies must have left them
   MatchSegs segs = {d_seg, d_seg + (n_seg + 1), d_seg + 2 * (n_seg + 1), d_seg + 3 * (n_seg + 1), n_seg};
-  return match_launch(h, metric, q, nq_rows, t, nt_rows, dim, 1, 0, (const MatchWG*)dp, (unsigned)wgs.size(), n_out, segs, w,
+  int64_t longest = 0;
+  for (int s = 0; s < n_seg; ++s) longest = (t_end_host[s] - t_beg_host[s]) > longest ? (t_end_host[s] - t_beg_host[s]) : longest;
+  return match_launch(h, metric, q, nq_rows, t, nt_rows, dim, 1, 0, 256, longest, (const MatchWG*)dp, (unsigned)wgs.size(), n_out, segs, w,
                       idx1, idx2, d1, d2);
 }
 
