@@ -390,6 +390,206 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(KNN_WAVES, 
   }
 }
 
+// ------------------------------------------------------------------------------------ L2 / uint8, operands straight from L2
+// The large single-pair case (dim 128, tens of thousands of queries).  k_knn2_u8 above stages the train rows through
+// LDS for the four waves of a workgroup and pays for it with a barrier and an exposed load per 128 rows (44 % of the
+// wave time waiting at 2 waves per SIMD).  Here the pre-pass stores the train set in MFMA operand order - per
+// 32-row tile and 32-byte k-slice the 64 lanes' 16-byte pieces back to back, 1 KiB per load instruction = 8 full
+// lines - and every wave fetches its A operands with plain global loads one tile ahead: no LDS, no barrier, the waves
+// of a workgroup are independent (they hit the same lines in the CU's L1).  TN_i travels with the tile in register
+// order (16 values per half-wave); TH = TN >> 1 and the parity bit are taken from it in registers.
+__global__ __launch_bounds__(256) void k_train_tile_u8(const uint8_t* __restrict__ x, int64_t n, uint8_t* __restrict__ xt,
+                                                       int* __restrict__ tn_t) {
+  const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t r = t >> 3;                               // row (up to the end of the last 32-row tile)
+  const int gi = (int)(t & 7);                            // 16-byte piece of the row: k-slice gi >> 1, half gi & 1
+  const int64_t n_pad = (n + 31) & ~(int64_t)31;
+  if (r >= n_pad) return;
+  uint4 v = make_uint4(0u, 0u, 0u, 0u);
+  int s = 0;
+  if (r < n) {
+    v = *(const uint4*)(x + r * 128 + gi * 16);
+    v.x ^= 0x80808080u; v.y ^= 0x80808080u; v.z ^= 0x80808080u; v.w ^= 0x80808080u;
+    const uint32_t wds[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+      for (int sh = 0; sh < 32; sh += 8) {
+        const int b = (int)(int8_t)((wds[q] >> sh) & 0xFFu) + 1;
+        s += b * b;
+      }
+  }
+  const int64_t tile = r >> 5;
+  const int l31 = (int)(r & 31);
+  *(uint4*)(xt + (((tile * 4 + (gi >> 1)) * 64) + (gi & 1) * 32 + l31) * 16) = v;
+  s += __shfl_xor(s, 1, 64); s += __shfl_xor(s, 2, 64); s += __shfl_xor(s, 4, 64);     // the 8 lanes of a row are adjacent and aligned
+  if (gi == 0) {
+    // accumulator register rr of half-wave hh holds row (rr & 3) + 8 (rr >> 2) + 4 hh of the tile
+    const int hh = (l31 >> 2) & 1, rr = (l31 & 3) + 4 * (l31 >> 3);
+    tn_t[(tile * 2 + hh) * 16 + rr] = (r < n) ? (s - 128) : 2 * SENT_TH;
+  }
+}
+
+template <int QB>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_knn2_u8_direct(
+    const uint8_t* __restrict__ q, int64_t nq, const uint8_t* __restrict__ xt, int64_t nt, const int* __restrict__ tn_t,
+    const int* __restrict__ qn, int nsplit, int64_t rows_per_split, Cand* __restrict__ part, int* u2g) {
+  constexpr int KS = 4, DIM = 128;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, half = lane >> 5, l31 = lane & 31;
+  // Workgroup -> (split, query block), split-major over the workgroups of one XCD (round-robin placement: XCD = b % 8):
+  // an XCD then streams one or two train splits (<= 2.6 MB at 50k rows) out of its own 4 MB L2 instead of all of them
+  // out of the Infinity Cache.  Speed only - any mapping gives the same result.
+  const int nb = gridDim.x, xcd = blockIdx.x & 7, per = nb >> 3, rem = nb & 7;
+  const int id = xcd * per + (xcd < rem ? xcd : rem) + (blockIdx.x >> 3);
+  const int n_qblocks = nb / nsplit;
+  const int split = id / n_qblocks;
+  const int64_t qblock = id - split * n_qblocks;
+  const int64_t t_beg = (int64_t)split * rows_per_split;                 // a multiple of 128
+  const int64_t t_end = (t_beg + rows_per_split) < nt ? (t_beg + rows_per_split) : nt;
+  const int64_t q0 = qblock * (4 * QB * 32) + (int64_t)w * (QB * 32);
+  if (q0 >= nq) return;                                                  // waves are independent: no barrier below
+
+  v4i bq[QB][KS];
+  int qnv[QB];
+#pragma unroll
+  for (int qb = 0; qb < QB; ++qb) {
+    const int64_t qi = q0 + qb * 32 + l31;
+    const bool ok = qi < nq;
+    qnv[qb] = ok ? qn[qi] : 0;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      v4i v = {0, 0, 0, 0};
+      if (ok) v = *(const v4i*)(q + qi * DIM + ks * 32 + half * 16);
+      bq[qb][ks] = v ^ 0x7F7F7F7F;
+    }
+  }
+  int g1i[QB], g2i[QB], g1k[QB], g2k[QB];
+  int m1[QB][2], m2[QB][2];
+  int thr[QB], u2_seen[QB], u2_sent[QB];
+#pragma unroll
+  for (int qb = 0; qb < QB; ++qb) {
+    g1k[qb] = 0x7FFFFFFF; g2k[qb] = 0x7FFFFFFF; g1i[qb] = -1; g2i[qb] = -1;
+    thr[qb] = (q0 + qb * 32 + l31 < nq) ? 0x7FFFFFFF : (int)0x80000000;
+    u2_seen[qb] = u2_sent[qb] = 0x7FFFFFFF;
+  }
+  const int64_t tile0 = t_beg >> 5;
+  const int n_tiles = t_end > t_beg ? (int)((t_end - t_beg + 31) >> 5) : 0;
+
+  v4i at[2][KS];
+  v16i tn[2];
+  auto load_tile = [&](int64_t tile, int set) {
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) at[set][ks] = *(const v4i*)(xt + ((tile * 4 + ks) * 64 + lane) * 16);
+    const int4* p = (const int4*)(tn_t + (tile * 2 + half) * 16);
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int4 kk = p[g];
+      tn[set][4 * g] = kk.x; tn[set][4 * g + 1] = kk.y; tn[set][4 * g + 2] = kk.z; tn[set][4 * g + 3] = kk.w;
+    }
+  };
+  // one tile = QB steps; the ranking of step s - 1 is issued in the gaps between the MFMAs of step s, the last step's
+  // ranking after the tile (see k_knn2_u8 for the ranking itself)
+  auto do_tile = [&](int t, int set) __attribute__((always_inline)) {
+    // always issued (the last tile fetches itself again): with the loads under a condition the compiler has to pick ONE
+    // s_waitcnt count for both paths and picks one that also waits for two of the loads just issued
+    load_tile(tile0 + (t + 1 < n_tiles ? t + 1 : t), set ^ 1);
+    if ((t & 7) == 0) {
+#pragma unroll
+      for (int qb = 0; qb < QB; ++qb) { m1[qb][0] = m1[qb][1] = 0x7FFFFFFF; m2[qb][0] = m2[qb][1] = 0x7FFFFFFF; }
+    }
+    v16i th;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) th[r] = tn[set][r] >> 1;
+    const int wbase = ((t & 7) << 5) | (4 * half);        // row inside the 256-row window of register 0
+    v16i acc[2];
+    int gm[4];
+    auto rank_group_min = [&](const v16i& a, int g) {
+      gm[g] = min(min(min(a[4 * g], a[4 * g + 1]), a[4 * g + 2]), a[4 * g + 3]);
+    };
+    auto rank_finish = [&](const v16i& a, int qb) {
+      const int mn = min(min(min(gm[0], gm[1]), gm[2]), gm[3]);
+      if (__builtin_amdgcn_ballot_w64(mn < thr[qb]) == 0ull) return;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        if (__builtin_amdgcn_ballot_w64(gm[g] < thr[qb]) == 0ull) continue;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int r = 4 * g + j;
+          const int key = (a[r] << 9) + (((tn[set][r] & 1) << 8) + (wbase + 8 * g + j));
+          int nm2;
+          asm("v_med3_i32 %0, %1, %2, %3" : "=v"(nm2) : "v"(m1[qb][r & 1]), "v"(m2[qb][r & 1]), "v"(key));
+          m2[qb][r & 1] = nm2;
+          m1[qb][r & 1] = min(m1[qb][r & 1], key);
+        }
+      }
+    };
+#pragma unroll
+    for (int qb = 0; qb < QB; ++qb) {
+      const v16i& prev = acc[(qb - 1) & 1];
+      acc[qb & 1] = th;
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        acc[qb & 1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(at[set][ks], bq[qb][ks], acc[qb & 1], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (qb > 0) { rank_group_min(prev, ks); __builtin_amdgcn_sched_barrier(0); }
+      }
+      if (qb > 0) rank_finish(prev, qb - 1);
+    }
+#pragma unroll
+    for (int g = 0; g < 4; ++g) rank_group_min(acc[(QB - 1) & 1], g);
+    rank_finish(acc[(QB - 1) & 1], QB - 1);
+    if ((t & 7) == 7 || t + 1 == n_tiles) {
+      const int cbase = (int)(t_beg + (int64_t)(t & ~7) * 32);      // train index of the window's first row
+      static_for<0, QB>([&](auto qbc) __attribute__((always_inline)) {
+        constexpr int qb = decltype(qbc)::value;
+        const int lo = min(m1[qb][0], m1[qb][1]), hi = max(m1[qb][0], m1[qb][1]);
+        const int second = min(hi, min(m2[qb][0], m2[qb][1]));
+        static_for<0, 2>([&](auto sc) __attribute__((always_inline)) {
+          const int m = decltype(sc)::value == 0 ? lo : second;
+          const bool ok = (m >> 8) < 2 * SENT_TH;
+          const int d2 = (m >> 8) + qnv[qb];
+          const int idx = cbase + (m & 0xFF);
+          const bool c1 = ok && d2 < g1k[qb], c2 = ok && !c1 && d2 < g2k[qb];
+          g2k[qb] = c1 ? g1k[qb] : (c2 ? d2 : g2k[qb]);
+          g2i[qb] = c1 ? g1i[qb] : (c2 ? idx : g2i[qb]);
+          g1k[qb] = c1 ? d2 : g1k[qb];
+          g1i[qb] = c1 ? idx : g1i[qb];
+        });
+        const int o1 = __shfl_xor(g1k[qb], 32, 64), o2 = __shfl_xor(g2k[qb], 32, 64);
+        int u2 = min(min(g2k[qb], o2), max(g1k[qb], o1));
+        u2 = min(u2, u2_seen[qb]);
+        if (half == 0 && thr[qb] != (int)0x80000000 && u2 < u2_sent[qb]) {
+          u2_seen[qb] = atomicMin(u2g + (q0 + qb * 32 + l31), u2);
+          u2_sent[qb] = u2;
+        }
+        u2 = min(u2, __shfl_xor(u2, 32, 64));
+        if (thr[qb] != (int)0x80000000) thr[qb] = (u2 == 0x7FFFFFFF) ? 0x7FFFFFFF : ((u2 - qnv[qb]) >> 1) + 1;
+      });
+    }
+  };
+  if (n_tiles > 0) load_tile(tile0, 0);
+  for (int t = 0; t < n_tiles; t += 2) {
+    do_tile(t, 0);
+    if (t + 1 < n_tiles) do_tile(t + 1, 1);
+  }
+#pragma unroll
+  for (int qb = 0; qb < QB; ++qb) {
+    const int o1k = __shfl_xor(g1k[qb], 32, 64), o1i = __shfl_xor(g1i[qb], 32, 64);
+    const int o2k = __shfl_xor(g2k[qb], 32, 64), o2i = __shfl_xor(g2i[qb], 32, 64);
+    float b1d = 3.0e38f, b2d = 3.0e38f; int b1i = -1, b2i = -1;
+    top2_insert((float)g1k[qb], g1i[qb], b1d, b1i, b2d, b2i);
+    top2_insert((float)g2k[qb], g2i[qb], b1d, b1i, b2d, b2i);
+    top2_insert((float)o1k, o1i, b1d, b1i, b2d, b2i);
+    top2_insert((float)o2k, o2i, b1d, b1i, b2d, b2i);
+    const int64_t qi = q0 + qb * 32 + l31;
+    if (half == 0 && qi < nq) {
+      Cand* o = part + ((int64_t)split * nq + qi) * 2;
+      o[0].d = b1i >= 0 ? b1d : 0.0f; o[0].i = b1i;
+      o[1].d = b2i >= 0 ? b2d : 0.0f; o[1].i = b2i;
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------------ generic VALU kernel
 // METRIC 1: float32, d^2 accumulated over k ascending with separately rounded multiply and add (the
 // oracle's stated order), distance = sqrtf(d^2).  METRIC 2: Hamming popcount over dim bytes (dim % 4 == 0).
@@ -624,8 +824,8 @@ static MatchWs match_ws_carve(char* ws, int64_t n_out, int64_t nt_rows, int64_t 
   MatchWs w;
   int64_t off = 0;
   w.part = (Cand*)(ws + off); off += align_up(8 * n_out * 2 * (int64_t)sizeof(Cand), 256);   // nsplit <= 8
-  w.tf = (uint8_t*)(ws + off); off += align_up((nt_rows + 1) * 128, 256);                       // int8 copy of the train rows + padding row (dim <= 128)
-  w.th = (int*)(ws + off); off += align_up((nt_rows + 1) * 4, 256);
+  w.tf = (uint8_t*)(ws + off); off += align_up((nt_rows + 32) * 128, 256);                      // int8 copy of the train rows + padding (dim <= 128)
+  w.th = (int*)(ws + off); off += align_up((nt_rows + 32) * 4, 256);
   w.par = (int*)(ws + off); off += align_up((nt_rows + 1) * 4, 256);
   w.qn = (int*)(ws + off); off += align_up(nq_rows * 4, 256);
   w.u2 = (int*)(ws + off); off += align_up(n_out * 4, 256);                                     // shared candidate thresholds (k_knn2_u8)
@@ -654,17 +854,24 @@ static int match_launch(sfm_ctx* h, int metric, const void* q, int64_t nq_rows, 
   if (wg)   // segments choose their own number of splits: slots a segment does not use must read as "empty" (i = -1)
     SFM_HIP(h, hipMemsetAsync(w.part, 0xFF, (size_t)8 * n_out * 2 * sizeof(Cand), h->stream));
   if (metric == SFM_METRIC_L2_U8) {
-    hipLaunchKernelGGL(k_train_prep_u8, dim3(cdiv((nt_rows + 1) * (dim >> 4), 256)), dim3(256), 0, h->stream, t8, nt_rows, dim, w.tf, w.th, w.par);
-    hipLaunchKernelGGL(k_row_norm_u8, dim3(cdiv(nq_rows * (dim >> 4), 256)), dim3(256), 0, h->stream, q8, nq_rows, dim, 0x7F, 0, w.qn);
     const bool qb4 = qpw == 512;
+    const char* d_env = getenv("SFM_MATCH_DIRECT");        // test / tuning knob: "0" = the LDS kernel also for the large case
+    const bool direct = qb4 && !(d_env && d_env[0] == '0');
+    if (direct)
+      hipLaunchKernelGGL(k_train_tile_u8, dim3(cdiv(((nt_rows + 31) & ~(int64_t)31) * 8, 256)), dim3(256), 0, h->stream, t8, nt_rows, w.tf, w.th);
+    else
+      hipLaunchKernelGGL(k_train_prep_u8, dim3(cdiv((nt_rows + 1) * (dim >> 4), 256)), dim3(256), 0, h->stream, t8, nt_rows, dim, w.tf, w.th, w.par);
+    hipLaunchKernelGGL(k_row_norm_u8, dim3(cdiv(nq_rows * (dim >> 4), 256)), dim3(256), 0, h->stream, q8, nq_rows, dim, 0x7F, 0, w.qn);
     // the candidate filter pays once the queries see a few thousand train rows (see k_knn2_u8); below that it is 10
     // operations per tile for nothing
     const char* f_env = getenv("SFM_MATCH_FILTER");        // test / tuning knob: "0" off, "1" on
     const bool filter = f_env ? f_env[0] == '1' : filter_rows >= 2048;
-    if (filter) SFM_HIP(h, hipMemsetAsync(w.u2, 0x7F, (size_t)n_out * sizeof(int), h->stream));      // "no bound yet"
+    if (filter || direct) SFM_HIP(h, hipMemsetAsync(w.u2, 0x7F, (size_t)n_out * sizeof(int), h->stream));      // "no bound yet"
     sfm_prof_begin(h, SFM_PROF_KNN);
 #define KNN_LAUNCH(KS, QB, F) hipLaunchKernelGGL((k_knn2_u8<KS, QB, F>), dim3(grid), dim3(256), 0, h->stream, q8, nq_rows, w.tf, nt_rows, w.th, w.par, w.qn, nsplit, rps, wg, n_out, w.part, w.u2)
-    if (filter) {
+    if (direct) {
+      hipLaunchKernelGGL((k_knn2_u8_direct<4>), dim3(grid), dim3(256), 0, h->stream, q8, nq_rows, w.tf, nt_rows, w.th, w.qn, nsplit, rps, w.part, w.u2);
+    } else if (filter) {
       if (qb4) KNN_LAUNCH(4, 4, true); else if (dim == 128) KNN_LAUNCH(4, 2, true); else if (dim == 64) KNN_LAUNCH(2, 2, true); else KNN_LAUNCH(1, 2, true);
     } else {
       if (qb4) KNN_LAUNCH(4, 4, false); else if (dim == 128) KNN_LAUNCH(4, 2, false); else if (dim == 64) KNN_LAUNCH(2, 2, false); else KNN_LAUNCH(1, 2, false);

@@ -14,7 +14,7 @@ out = sys.argv[1]
 acc = collections.defaultdict(list)
 for f in glob.glob(out + "/p*/**/*counter_collection.csv", recursive=True):
     for row in csv.DictReader(open(f)):
-        if "k_knn2_u8<" in row["Kernel_Name"] or row["Kernel_Name"].startswith("void k_knn2_u8<"):
+        if "k_knn2_u8<" in row["Kernel_Name"] or "k_knn2_u8_direct<" in row["Kernel_Name"]:
             acc[row["Counter_Name"]].append(float(row["Counter_Value"]))
 m = {k: sum(v) / len(v) for k, v in acc.items()}
 for k in sorted(m): print(f"{k:32s} n={len(acc[k]):3d} mean={m[k]:16.1f}")
