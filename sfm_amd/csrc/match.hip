@@ -399,11 +399,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(KNN_WAVES, 
 // of a workgroup are independent (they hit the same lines in the CU's L1).  TN_i travels with the tile in register
 // order (16 values per half-wave); TH = TN >> 1 and the parity bit are taken from it in registers.
 __global__ __launch_bounds__(256) void k_train_tile_u8(const uint8_t* __restrict__ x, int64_t n, uint8_t* __restrict__ xt,
-                                                       int* __restrict__ tn_t) {
+                                                       int* __restrict__ th_t, int* __restrict__ pb_t) {
   const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
   const int64_t r = t >> 3;                               // row (up to the end of the last 32-row tile)
   const int gi = (int)(t & 7);                            // 16-byte piece of the row: k-slice gi >> 1, half gi & 1
-  const int64_t n_pad = (n + 31) & ~(int64_t)31;
+  const int64_t n_pad = (n + 31) & ~(int64_t)31;           // whole tiles = whole waves: every shuffle below sees its partners
   if (r >= n_pad) return;
   uint4 v = make_uint4(0u, 0u, 0u, 0u);
   int s = 0;
@@ -423,18 +423,23 @@ __global__ __launch_bounds__(256) void k_train_tile_u8(const uint8_t* __restrict
   const int l31 = (int)(r & 31);
   *(uint4*)(xt + (((tile * 4 + (gi >> 1)) * 64) + (gi & 1) * 32 + l31) * 16) = v;
   s += __shfl_xor(s, 1, 64); s += __shfl_xor(s, 2, 64); s += __shfl_xor(s, 4, 64);     // the 8 lanes of a row are adjacent and aligned
-  if (gi == 0) {
-    // accumulator register rr of half-wave hh holds row (rr & 3) + 8 (rr >> 2) + 4 hh of the tile
-    const int hh = (l31 >> 2) & 1, rr = (l31 & 3) + 4 * (l31 >> 3);
-    tn_t[(tile * 2 + hh) * 16 + rr] = (r < n) ? (s - 128) : 2 * SENT_TH;
-  }
+  const int tn = (r < n) ? (s - 128) : 2 * SENT_TH;
+  // accumulator register rr of half-wave hh holds row (rr & 3) + 8 (rr >> 2) + 4 hh of the tile
+  const int hh = (l31 >> 2) & 1, rr = (l31 & 3) + 4 * (l31 >> 3);
+  if (gi == 0) th_t[(tile * 2 + hh) * 16 + rr] = tn >> 1;
+  // parity bits: bit rr of word (tile, hh).  A wave holds 8 rows: rows 8k..8k+3 (hh = 0) and 8k+4..8k+7 (hh = 1) of one
+  // k = rr >> 2; the four rows of a group OR their bits together, lane gi == 0 of the group's first row adds them in.
+  int bit = (gi == 0) ? ((tn & 1) << rr) : 0;
+  bit |= __shfl_xor(bit, 8, 64); bit |= __shfl_xor(bit, 16, 64);                         // rows l31 ^ 1, l31 ^ 2: same hh, same rr >> 2
+  if (gi == 0 && (l31 & 3) == 0) atomicOr(pb_t + tile * 2 + hh, bit);
 }
 
 template <int QB>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_knn2_u8_direct(
-    const uint8_t* __restrict__ q, int64_t nq, const uint8_t* __restrict__ xt, int64_t nt, const int* __restrict__ tn_t,
-    const int* __restrict__ qn, int nsplit, int64_t rows_per_split, Cand* __restrict__ part, int* u2g) {
+    const uint8_t* __restrict__ q, int64_t nq, const uint8_t* __restrict__ xt, int64_t nt, const int* __restrict__ th_t,
+    const int* __restrict__ pb_t, const int* __restrict__ qn, int nsplit, int64_t rows_per_split, Cand* __restrict__ part, int* u2g) {
   constexpr int KS = 4, DIM = 128;
+  static_assert(QB % 2 == 0, "the two accumulators alternate by step across tiles");
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, half = lane >> 5, l31 = lane & 31;
   // Workgroup -> (split, query block), split-major over the workgroups of one XCD (round-robin placement: XCD = b % 8):
   // an XCD then streams one or two train splits (<= 2.6 MB at 50k rows) out of its own 4 MB L2 instead of all of them
@@ -450,141 +455,185 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   if (q0 >= nq) return;                                                  // waves are independent: no barrier below
 
   v4i bq[QB][KS];
-  int qnv[QB];
+  // What only the window flush touches (the running best two, the posted bound, QN) lives in LDS between flushes - the
+  // kernel has no other use for LDS, and the registers pay for a second tile of operands in flight.
+  enum { ST_G1K = 0, ST_G2K = QB, ST_G1I = 2 * QB, ST_G2I = 3 * QB, ST_SENT = 4 * QB, ST_QN = 5 * QB, ST_N = 6 * QB };
+  __shared__ int s_st[ST_N][256];
+  int m1[QB][2], m2[QB][2];
+  int thr[QB];
+  int u2_seen[QB], u2_next[QB];      // the other splits' bounds: in use / on their way
+  const int* u2_mine = u2g + q0 + l31;      // lanes past the last query read on into the workspace (fix_list follows): never used
 #pragma unroll
   for (int qb = 0; qb < QB; ++qb) {
     const int64_t qi = q0 + qb * 32 + l31;
     const bool ok = qi < nq;
-    qnv[qb] = ok ? qn[qi] : 0;
+    s_st[ST_QN + qb][tid] = ok ? qn[qi] : 0;
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
       v4i v = {0, 0, 0, 0};
       if (ok) v = *(const v4i*)(q + qi * DIM + ks * 32 + half * 16);
       bq[qb][ks] = v ^ 0x7F7F7F7F;
     }
-  }
-  int g1i[QB], g2i[QB], g1k[QB], g2k[QB];
-  int m1[QB][2], m2[QB][2];
-  int thr[QB], u2_seen[QB], u2_sent[QB];
-#pragma unroll
-  for (int qb = 0; qb < QB; ++qb) {
-    g1k[qb] = 0x7FFFFFFF; g2k[qb] = 0x7FFFFFFF; g1i[qb] = -1; g2i[qb] = -1;
-    thr[qb] = (q0 + qb * 32 + l31 < nq) ? 0x7FFFFFFF : (int)0x80000000;
-    u2_seen[qb] = u2_sent[qb] = 0x7FFFFFFF;
+    s_st[ST_G1K + qb][tid] = 0x7FFFFFFF; s_st[ST_G2K + qb][tid] = 0x7FFFFFFF; s_st[ST_G1I + qb][tid] = -1; s_st[ST_G2I + qb][tid] = -1;
+    s_st[ST_SENT + qb][tid] = 0x7FFFFFFF;
+    thr[qb] = ok ? 0x7FFFFFFF : (int)0x80000000;
+    u2_seen[qb] = u2_next[qb] = 0x7FFFFFFF;
+    m1[qb][0] = m1[qb][1] = 0x7FFFFFFF; m2[qb][0] = m2[qb][1] = 0x7FFFFFFF;
   }
   const int64_t tile0 = t_beg >> 5;
   const int n_tiles = t_end > t_beg ? (int)((t_end - t_beg + 31) >> 5) : 0;
 
   v4i at[2][KS];
-  v16i tn[2];
+  v16i th[2];           // accumulator start values TN >> 1 of the 16 train rows a lane's registers hold
+  int pb[2];            // their parity bits (bit r = TN & 1 of register r)
   auto load_tile = [&](int64_t tile, int set) {
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) at[set][ks] = *(const v4i*)(xt + ((tile * 4 + ks) * 64 + lane) * 16);
-    const int4* p = (const int4*)(tn_t + (tile * 2 + half) * 16);
+    const int4* p = (const int4*)(th_t + (tile * 2 + half) * 16);
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
       const int4 kk = p[g];
-      tn[set][4 * g] = kk.x; tn[set][4 * g + 1] = kk.y; tn[set][4 * g + 2] = kk.z; tn[set][4 * g + 3] = kk.w;
+      th[set][4 * g] = kk.x; th[set][4 * g + 1] = kk.y; th[set][4 * g + 2] = kk.z; th[set][4 * g + 3] = kk.w;
+    }
+    pb[set] = pb_t[tile * 2 + half];
+  };
+  // The ranking of a step's accumulators (see k_knn2_u8) is issued in the gaps between the MFMAs of the NEXT step, across
+  // tile boundaries too: what it needs from its own tile are the parity word and the window position, one register each.
+  int gm[4];
+  auto rank_group_min = [&](const v16i& a, int g) {
+    gm[g] = min(min(min(a[4 * g], a[4 * g + 1]), a[4 * g + 2]), a[4 * g + 3]);
+  };
+  auto rank_finish = [&](const v16i& a, int qb, int pbits, int wbase) {
+    const int mn = min(min(min(gm[0], gm[1]), gm[2]), gm[3]);
+    if (__builtin_amdgcn_ballot_w64(mn < thr[qb]) == 0ull) return;                 // wave-uniform: nothing in this tile can enter a top-2
+    int wb = wbase;
+    asm volatile("" : "+v"(wb));            // keeps the 16 row numbers from being formed ahead of time for every tile
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      if (__builtin_amdgcn_ballot_w64(gm[g] < thr[qb]) == 0ull) continue;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int r = 4 * g + j;
+        // ((2 acc + parity) << 8) | row in window = ((d^2 - QN) << 8) | row
+        const int key = (a[r] << 9) + ((((pbits >> r) & 1) << 8) + (wb + 8 * g + j));
+        int nm2;
+        asm("v_med3_i32 %0, %1, %2, %3" : "=v"(nm2) : "v"(m1[qb][r & 1]), "v"(m2[qb][r & 1]), "v"(key));
+        m2[qb][r & 1] = nm2;
+        m1[qb][r & 1] = min(m1[qb][r & 1], key);
+      }
     }
   };
-  // one tile = QB steps; the ranking of step s - 1 is issued in the gaps between the MFMAs of step s, the last step's
-  // ranking after the tile (see k_knn2_u8 for the ranking itself)
-  auto do_tile = [&](int t, int set) __attribute__((always_inline)) {
-    // always issued (the last tile fetches itself again): with the loads under a condition the compiler has to pick ONE
-    // s_waitcnt count for both paths and picks one that also waits for two of the loads just issued
-    load_tile(tile0 + (t + 1 < n_tiles ? t + 1 : t), set ^ 1);
-    if ((t & 7) == 0) {
+  // merge the finished 256-row window whose first tile is tw into the running best two, post / pick up the bound
+  auto flush = [&](int tw) __attribute__((always_inline)) {
+    const int cbase = (int)(t_beg + (int64_t)tw * 32);                   // train index of the window's first row
+    int g1k[QB], g2k[QB], g1i[QB], g2i[QB], qnq[QB], sent[QB];
 #pragma unroll
-      for (int qb = 0; qb < QB; ++qb) { m1[qb][0] = m1[qb][1] = 0x7FFFFFFF; m2[qb][0] = m2[qb][1] = 0x7FFFFFFF; }
+    for (int qb = 0; qb < QB; ++qb) {                                    // all LDS reads first: one round trip, not one per value
+      g1k[qb] = s_st[ST_G1K + qb][tid]; g2k[qb] = s_st[ST_G2K + qb][tid]; g1i[qb] = s_st[ST_G1I + qb][tid];
+      g2i[qb] = s_st[ST_G2I + qb][tid]; qnq[qb] = s_st[ST_QN + qb][tid]; sent[qb] = s_st[ST_SENT + qb][tid];
     }
-    v16i th;
+    int u2[QB];
+    static_for<0, QB>([&](auto qbc) __attribute__((always_inline)) {
+      constexpr int qb = decltype(qbc)::value;
+      // keys carry the row index, so they are totally ordered: best two of the four
+      const int lo = min(m1[qb][0], m1[qb][1]), hi = max(m1[qb][0], m1[qb][1]);
+      const int second = min(hi, min(m2[qb][0], m2[qb][1]));
+      static_for<0, 2>([&](auto sc) __attribute__((always_inline)) {
+        const int m = decltype(sc)::value == 0 ? lo : second;
+        const bool ok = (m >> 8) < 2 * SENT_TH;            // not a padding row or an empty slot
+        const int d2 = (m >> 8) + qnq[qb];
+        const int idx = cbase + (m & 0xFF);
+        // selects, not branches (see k_knn2_u8)
+        const bool c1 = ok && d2 < g1k[qb], c2 = ok && !c1 && d2 < g2k[qb];
+        g2k[qb] = c1 ? g1k[qb] : (c2 ? d2 : g2k[qb]);
+        g2i[qb] = c1 ? g1i[qb] : (c2 ? idx : g2i[qb]);
+        g1k[qb] = c1 ? d2 : g1k[qb];
+        g1i[qb] = c1 ? idx : g1i[qb];
+      });
+      m1[qb][0] = m1[qb][1] = 0x7FFFFFFF; m2[qb][0] = m2[qb][1] = 0x7FFFFFFF;
+    });
+    int o1[QB], o2[QB];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) th[r] = tn[set][r] >> 1;
-    const int wbase = ((t & 7) << 5) | (4 * half);        // row inside the 256-row window of register 0
-    v16i acc[2];
-    int gm[4];
-    auto rank_group_min = [&](const v16i& a, int g) {
-      gm[g] = min(min(min(a[4 * g], a[4 * g + 1]), a[4 * g + 2]), a[4 * g + 3]);
-    };
-    auto rank_finish = [&](const v16i& a, int qb) {
-      const int mn = min(min(min(gm[0], gm[1]), gm[2]), gm[3]);
-      if (__builtin_amdgcn_ballot_w64(mn < thr[qb]) == 0ull) return;
+    for (int qb = 0; qb < QB; ++qb) { o1[qb] = __shfl_xor(g1k[qb], 32, 64); o2[qb] = __shfl_xor(g2k[qb], 32, 64); }
 #pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        if (__builtin_amdgcn_ballot_w64(gm[g] < thr[qb]) == 0ull) continue;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const int r = 4 * g + j;
-          const int key = (a[r] << 9) + (((tn[set][r] & 1) << 8) + (wbase + 8 * g + j));
-          int nm2;
-          asm("v_med3_i32 %0, %1, %2, %3" : "=v"(nm2) : "v"(m1[qb][r & 1]), "v"(m2[qb][r & 1]), "v"(key));
-          m2[qb][r & 1] = nm2;
-          m1[qb][r & 1] = min(m1[qb][r & 1], key);
-        }
+    for (int qb = 0; qb < QB; ++qb) {
+      s_st[ST_G1K + qb][tid] = g1k[qb]; s_st[ST_G2K + qb][tid] = g2k[qb]; s_st[ST_G1I + qb][tid] = g1i[qb]; s_st[ST_G2I + qb][tid] = g2i[qb];
+      // second-best d^2 of the query over both half-waves and over the other train splits (see k_knn2_u8)
+      u2[qb] = min(min(min(g2k[qb], o2[qb]), max(g1k[qb], o1[qb])), u2_seen[qb]);
+      if (half == 0 && thr[qb] != (int)0x80000000 && u2[qb] < sent[qb]) {
+        // posted with an atomic the compiler does not see (nothing waits for it), picked up by the loads at the top of
+        // every tile: a returning atomic here, on one path only, makes the compiler wait with vmcnt(0) in every tile
+        asm volatile("global_atomic_smin %0, %1, off" ::"v"(u2g + (q0 + qb * 32 + l31)), "v"(u2[qb]) : "memory");
+        s_st[ST_SENT + qb][tid] = u2[qb];
       }
-    };
+    }
+#pragma unroll
+    for (int qb = 0; qb < QB; ++qb) {
+      const int u = min(u2[qb], __shfl_xor(u2[qb], 32, 64));
+      if (thr[qb] != (int)0x80000000) thr[qb] = (u == 0x7FFFFFFF) ? 0x7FFFFFFF : ((u - qnq[qb]) >> 1) + 1;
+    }
+  };
+  v16i acc[2];
+  auto do_tile = [&](int t, int set) __attribute__((always_inline)) {
+    // one tile ahead (two measured the same), into the set the previous tile has just finished with.  Always issued (the
+    // last tile fetches itself again): with the loads under a condition the compiler has to pick ONE s_waitcnt count for
+    // both paths and picks one that also waits for some of the loads just issued
+    const int pset = set ^ 1;
+    const int pb_prev = pb[pset];                          // the previous tile's parity word, before its set is refilled
+    // the bounds the other splits have posted: fetched in EVERY tile (same number of loads on every path, see below), past
+    // the XCD's own L2 (device-scope load), used from the next tile on
+#pragma unroll
+    for (int qb = 0; qb < QB; ++qb) {
+      u2_seen[qb] = u2_next[qb];
+      u2_next[qb] = __hip_atomic_load(u2_mine + qb * 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    load_tile(tile0 + (t + 1 < n_tiles ? t + 1 : t), pset);
+    const int wb_prev = (((t - 1) & 7) << 5) | (4 * half), wb_cur = ((t & 7) << 5) | (4 * half);
 #pragma unroll
     for (int qb = 0; qb < QB; ++qb) {
       const v16i& prev = acc[(qb - 1) & 1];
-      acc[qb & 1] = th;
+      const bool have_prev = qb > 0 || t > 0;              // wave-uniform
+      acc[qb & 1] = th[set];
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks) {
         acc[qb & 1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(at[set][ks], bq[qb][ks], acc[qb & 1], 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
-        if (qb > 0) { rank_group_min(prev, ks); __builtin_amdgcn_sched_barrier(0); }
+        if (have_prev) { rank_group_min(prev, ks); __builtin_amdgcn_sched_barrier(0); }
       }
-      if (qb > 0) rank_finish(prev, qb - 1);
-    }
-#pragma unroll
-    for (int g = 0; g < 4; ++g) rank_group_min(acc[(QB - 1) & 1], g);
-    rank_finish(acc[(QB - 1) & 1], QB - 1);
-    if ((t & 7) == 7 || t + 1 == n_tiles) {
-      const int cbase = (int)(t_beg + (int64_t)(t & ~7) * 32);      // train index of the window's first row
-      static_for<0, QB>([&](auto qbc) __attribute__((always_inline)) {
-        constexpr int qb = decltype(qbc)::value;
-        const int lo = min(m1[qb][0], m1[qb][1]), hi = max(m1[qb][0], m1[qb][1]);
-        const int second = min(hi, min(m2[qb][0], m2[qb][1]));
-        static_for<0, 2>([&](auto sc) __attribute__((always_inline)) {
-          const int m = decltype(sc)::value == 0 ? lo : second;
-          const bool ok = (m >> 8) < 2 * SENT_TH;
-          const int d2 = (m >> 8) + qnv[qb];
-          const int idx = cbase + (m & 0xFF);
-          const bool c1 = ok && d2 < g1k[qb], c2 = ok && !c1 && d2 < g2k[qb];
-          g2k[qb] = c1 ? g1k[qb] : (c2 ? d2 : g2k[qb]);
-          g2i[qb] = c1 ? g1i[qb] : (c2 ? idx : g2i[qb]);
-          g1k[qb] = c1 ? d2 : g1k[qb];
-          g1i[qb] = c1 ? idx : g1i[qb];
-        });
-        const int o1 = __shfl_xor(g1k[qb], 32, 64), o2 = __shfl_xor(g2k[qb], 32, 64);
-        int u2 = min(min(g2k[qb], o2), max(g1k[qb], o1));
-        u2 = min(u2, u2_seen[qb]);
-        if (half == 0 && thr[qb] != (int)0x80000000 && u2 < u2_sent[qb]) {
-          u2_seen[qb] = atomicMin(u2g + (q0 + qb * 32 + l31), u2);
-          u2_sent[qb] = u2;
-        }
-        u2 = min(u2, __shfl_xor(u2, 32, 64));
-        if (thr[qb] != (int)0x80000000) thr[qb] = (u2 == 0x7FFFFFFF) ? 0x7FFFFFFF : ((u2 - qnv[qb]) >> 1) + 1;
-      });
+      if (qb > 0) rank_finish(prev, qb - 1, pb[set], wb_cur);
+      else if (t > 0) {
+        rank_finish(prev, QB - 1, pb_prev, wb_prev);
+        if ((t & 7) == 0) flush(t - 8);                    // the window that ended with the previous tile
+      }
     }
   };
   if (n_tiles > 0) load_tile(tile0, 0);
   for (int t = 0; t < n_tiles; t += 2) {
     do_tile(t, 0);
-    if (t + 1 < n_tiles) do_tile(t + 1, 1);
+    if (t + 1 >= n_tiles) break;
+    do_tile(t + 1, 1);
+  }
+  if (n_tiles > 0) {                                       // the last step's ranking and the last window
+    const int t = n_tiles - 1, set = t & 1;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) rank_group_min(acc[(QB - 1) & 1], g);
+    rank_finish(acc[(QB - 1) & 1], QB - 1, pb[set], ((t & 7) << 5) | (4 * half));
+    flush(t & ~7);
   }
 #pragma unroll
   for (int qb = 0; qb < QB; ++qb) {
-    const int o1k = __shfl_xor(g1k[qb], 32, 64), o1i = __shfl_xor(g1i[qb], 32, 64);
-    const int o2k = __shfl_xor(g2k[qb], 32, 64), o2i = __shfl_xor(g2i[qb], 32, 64);
+    const int g1k = s_st[ST_G1K + qb][tid], g2k = s_st[ST_G2K + qb][tid], g1i = s_st[ST_G1I + qb][tid], g2i = s_st[ST_G2I + qb][tid];
+    const int o1k = __shfl_xor(g1k, 32, 64), o1i = __shfl_xor(g1i, 32, 64);
+    const int o2k = __shfl_xor(g2k, 32, 64), o2i = __shfl_xor(g2i, 32, 64);
     float b1d = 3.0e38f, b2d = 3.0e38f; int b1i = -1, b2i = -1;
-    top2_insert((float)g1k[qb], g1i[qb], b1d, b1i, b2d, b2i);
-    top2_insert((float)g2k[qb], g2i[qb], b1d, b1i, b2d, b2i);
+    top2_insert((float)g1k, g1i, b1d, b1i, b2d, b2i);      // exact: d^2 < 2^24
+    top2_insert((float)g2k, g2i, b1d, b1i, b2d, b2i);
     top2_insert((float)o1k, o1i, b1d, b1i, b2d, b2i);
     top2_insert((float)o2k, o2i, b1d, b1i, b2d, b2i);
     const int64_t qi = q0 + qb * 32 + l31;
     if (half == 0 && qi < nq) {
       Cand* o = part + ((int64_t)split * nq + qi) * 2;
-      o[0].d = b1i >= 0 ? b1d : 0.0f; o[0].i = b1i;
+      o[0].d = b1i >= 0 ? b1d : 0.0f; o[0].i = b1i;        // d = d^2 (an exact integer below 2^24); k_merge_splits_u8 takes the root
       o[1].d = b2i >= 0 ? b2d : 0.0f; o[1].i = b2i;
     }
   }
@@ -858,7 +907,10 @@ static int match_launch(sfm_ctx* h, int metric, const void* q, int64_t nq_rows, 
     const char* d_env = getenv("SFM_MATCH_DIRECT");        // test / tuning knob: "0" = the LDS kernel also for the large case
     const bool direct = qb4 && !(d_env && d_env[0] == '0');
     if (direct)
-      hipLaunchKernelGGL(k_train_tile_u8, dim3(cdiv(((nt_rows + 31) & ~(int64_t)31) * 8, 256)), dim3(256), 0, h->stream, t8, nt_rows, w.tf, w.th);
+    {
+      SFM_HIP(h, hipMemsetAsync(w.par, 0, (size_t)(((nt_rows + 31) >> 5) * 2) * sizeof(int), h->stream));      // parity words are OR-ed together
+      hipLaunchKernelGGL(k_train_tile_u8, dim3(cdiv(((nt_rows + 31) & ~(int64_t)31) * 8, 256)), dim3(256), 0, h->stream, t8, nt_rows, w.tf, w.th, w.par);
+    }
     else
       hipLaunchKernelGGL(k_train_prep_u8, dim3(cdiv((nt_rows + 1) * (dim >> 4), 256)), dim3(256), 0, h->stream, t8, nt_rows, dim, w.tf, w.th, w.par);
     hipLaunchKernelGGL(k_row_norm_u8, dim3(cdiv(nq_rows * (dim >> 4), 256)), dim3(256), 0, h->stream, q8, nq_rows, dim, 0x7F, 0, w.qn);
@@ -870,7 +922,7 @@ static int match_launch(sfm_ctx* h, int metric, const void* q, int64_t nq_rows, 
     sfm_prof_begin(h, SFM_PROF_KNN);
 #define KNN_LAUNCH(KS, QB, F) hipLaunchKernelGGL((k_knn2_u8<KS, QB, F>), dim3(grid), dim3(256), 0, h->stream, q8, nq_rows, w.tf, nt_rows, w.th, w.par, w.qn, nsplit, rps, wg, n_out, w.part, w.u2)
     if (direct) {
-      hipLaunchKernelGGL((k_knn2_u8_direct<4>), dim3(grid), dim3(256), 0, h->stream, q8, nq_rows, w.tf, nt_rows, w.th, w.qn, nsplit, rps, w.part, w.u2);
+      hipLaunchKernelGGL((k_knn2_u8_direct<4>), dim3(grid), dim3(256), 0, h->stream, q8, nq_rows, w.tf, nt_rows, w.th, w.par, w.qn, nsplit, rps, w.part, w.u2);
     } else if (filter) {
       if (qb4) KNN_LAUNCH(4, 4, true); else if (dim == 128) KNN_LAUNCH(4, 2, true); else if (dim == 64) KNN_LAUNCH(2, 2, true); else KNN_LAUNCH(1, 2, true);
     } else {
