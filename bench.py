@@ -321,7 +321,7 @@ def main():
         if knn_cnt > 0:
             ops = 2.0 * 128 * (q_hi - q_lo) * n            # i8 multiply-adds of the distance GEMM, per launch
             ach = ops / (knn_ms / knn_cnt * 1e-3) / 1e12
-            mroof = {"kernel": "k_knn2_u8<4,2> (i8 MFMA distance + top-2)", "bound": "mfma", "achieved": round(ach, 1),
+            mroof = {"kernel": "k_knn2_u8_direct<4> (i8 MFMA distance + filtered top-2, operands straight from L2)", "bound": "mfma", "achieved": round(ach, 1),
                      "peak": I8_MFMA_PEAK_TOPS, "unit": "TOP/s", "frac": round(ach / I8_MFMA_PEAK_TOPS, 4),
                      "avg_us": round(knn_ms / knn_cnt * 1e3, 1), "traffic": None}
         matcher = {"metric": "descriptor-pairs/sec", "value": pairs / tm, "unit": "pairs/s",

@@ -178,6 +178,37 @@ def test_full_size_50k_all_rows(gpu_ready):
     assert np.array_equal(t, rt) and np.array_equal(d.cpu().numpy(), rd)
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("nq,nt,kind", [(16384, 2049, "sift"), (16400, 1017, "uniform"), (20001, 3, "sift"),
+                                        (16390, 4101, "far"), (17000, 6000, "dups")])
+def test_l2_u8_many_queries_kernel_edges(gpu_ready, nq, nt, kind):
+    """From 16,384 queries on (dim 128, one pair) the distances come from the LDS-free kernel (k_knn2_u8_direct: train
+    set re-tiled into MFMA operand order, candidate filter, ranking pipelined across tiles).  Its edges against the C
+    oracle, every row: a query count that is not a multiple of the 512-query workgroup, train sets that end inside a
+    32-row tile / a 256-row window / a split, three train rows only, rows far enough apart for the float32 re-ranking
+    (d^2 >= 2^22), and many exact duplicates (ties on d^2: lowest train index first)."""
+    import torch
+    from oracle import ba_c
+    from sfm_amd import synth, matcher
+    rng = np.random.default_rng(nq + nt)
+    if kind == "sift":
+        d1, d2 = synth.make_descriptors(nq, nt, seed=nq)
+        u1, u2 = d1.astype(np.uint8), d2.astype(np.uint8)
+    elif kind == "uniform":
+        u1 = rng.integers(0, 256, size=(nq, 128), dtype=np.uint8)
+        u2 = rng.integers(0, 256, size=(nt, 128), dtype=np.uint8)
+    elif kind == "far":
+        u1, u2 = far_apart_sets(nq, nt, 128, seed=5)
+    else:
+        base = rng.integers(0, 256, size=(40, 128), dtype=np.uint8)
+        u2 = base[rng.integers(0, 40, size=nt)]                     # every train row exists ~150 times
+        u1 = base[rng.integers(0, 40, size=nq)]
+        u1[::3] = np.clip(u1[::3].astype(np.int32) + rng.integers(-1, 2, size=u1[::3].shape), 0, 255).astype(np.uint8)
+    i1, i2, a, b = matcher.knn2(torch.from_numpy(u1).cuda(), torch.from_numpy(u2).cuda(), "l2")
+    got = (i1.cpu().numpy(), i2.cpu().numpy(), a.cpu().numpy(), b.cpu().numpy())
+    assert_knn_equal(got, ba_c.knn2_u8(u1, u2))
+
+
 # ------------------------------------------------------------------ batched (segmented) matching
 def _image_sets(sizes, seed, kind="sift", dim=128):
     from sfm_amd import synth

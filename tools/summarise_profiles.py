@@ -76,12 +76,12 @@ if rows:
 m = collections.defaultdict(list)
 for sub in ("msq1", "msq2"):
     for k, cs in counters(os.path.join(src, sub)).items():
-        if k.startswith("k_knn2_u8<"):                     # the distance kernel itself, not k_knn2_u8_rerank
+        if k.startswith("k_knn2_u8<") or k.startswith("k_knn2_u8_direct<"):      # the distance kernel itself, not k_knn2_u8_rerank
             for c, v in cs.items():
                 m[c] += v
 if m:
     with open(os.path.join(dst, f"{rnd}_pmc_matcher.txt"), "w") as fh:
-        fh.write("# k_knn2_u8<4,2>, 50k x 50k x 128 uint8, library built with -mllvm -amdgpu-mfma-vgpr-form (the shipped flags);\n"
+        fh.write("# k_knn2_u8_direct<4>, 50k x 50k x 128 uint8, library built with -mllvm -amdgpu-mfma-vgpr-form (the shipped flags);\n"
                  "# rocprofv3 --pmc <8 SQ counters> --kernel-trace -- python3 tools/run_matcher.py, two passes, mean per launch\n")
         for c in sorted(m):
             fh.write(f"{c:32s} n={len(m[c]):3d} mean={sum(m[c]) / len(m[c]):16.1f}\n")
