@@ -574,6 +574,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     }
   };
   v16i acc[2];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[1][r] = SENT_TH;         // "previous step" of the first one: padding rows, ranked and ignored
+  pb[1] = 0;
   auto do_tile = [&](int t, int set) __attribute__((always_inline)) {
     // one tile ahead (two measured the same), into the set the previous tile has just finished with.  Always issued (the
     // last tile fetches itself again): with the loads under a condition the compiler has to pick ONE s_waitcnt count for
@@ -591,19 +594,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     const int wb_prev = (((t - 1) & 7) << 5) | (4 * half), wb_cur = ((t & 7) << 5) | (4 * half);
 #pragma unroll
     for (int qb = 0; qb < QB; ++qb) {
-      const v16i& prev = acc[(qb - 1) & 1];
-      const bool have_prev = qb > 0 || t > 0;              // wave-uniform
+      const v16i& prev = acc[(qb - 1) & 1];                // the very first step ranks the padding values acc[1] starts with
       acc[qb & 1] = th[set];
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks) {
         acc[qb & 1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(at[set][ks], bq[qb][ks], acc[qb & 1], 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
-        if (have_prev) { rank_group_min(prev, ks); __builtin_amdgcn_sched_barrier(0); }
+        rank_group_min(prev, ks);
+        __builtin_amdgcn_sched_barrier(0);
       }
       if (qb > 0) rank_finish(prev, qb - 1, pb[set], wb_cur);
-      else if (t > 0) {
+      else {
         rank_finish(prev, QB - 1, pb_prev, wb_prev);
-        if ((t & 7) == 0) flush(t - 8);                    // the window that ended with the previous tile
+        if ((t & 7) == 0 && t > 0) flush(t - 8);           // the window that ended with the previous tile
       }
     }
   };
