@@ -462,7 +462,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   int m1[QB][2], m2[QB][2];
   int thr[QB];
   int u2_seen[QB], u2_next[QB];      // the other splits' bounds: in use / on their way
-  const int* u2_mine = u2g + q0 + l31;      // lanes past the last query read on into the workspace (fix_list follows): never used
+  // the bounds of a wave's QB x 32 queries are kept query-in-block major ([l31][qb]: this kernel is their only user), so
+  // that a lane fetches its QB values with QB / 2 eight-byte loads; lanes past the last query read values nobody posts
+  const int* u2_mine = u2g + q0 + l31 * QB;
 #pragma unroll
   for (int qb = 0; qb < QB; ++qb) {
     const int64_t qi = q0 + qb * 32 + l31;
@@ -484,17 +486,28 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   const int n_tiles = t_end > t_beg ? (int)((t_end - t_beg + 31) >> 5) : 0;
 
   v4i at[2][KS];
-  v16i th[2];           // accumulator start values TN >> 1 of the 16 train rows a lane's registers hold
-  int pb[2];            // their parity bits (bit r = TN & 1 of register r)
+  int4 thq[2];          // one quarter of the accumulator start values TN >> 1 of the tile's rows (see load_tile)
+  int pb[2];            // the rows' parity bits (bit r = TN & 1 of register r)
+  // quad_perm [c,c,c,c]: every lane of a quad reads the value of the quad's lane c
+#define QUAD_BCAST(x, c) __builtin_amdgcn_mov_dpp((x), (c) | ((c) << 2) | ((c) << 4) | ((c) << 6), 0xF, 0xF, true)
+  auto spread_th = [&](const int4& qv) {
+    v16i o;
+    o[0] = QUAD_BCAST(qv.x, 0); o[1] = QUAD_BCAST(qv.y, 0); o[2] = QUAD_BCAST(qv.z, 0); o[3] = QUAD_BCAST(qv.w, 0);
+    o[4] = QUAD_BCAST(qv.x, 1); o[5] = QUAD_BCAST(qv.y, 1); o[6] = QUAD_BCAST(qv.z, 1); o[7] = QUAD_BCAST(qv.w, 1);
+    o[8] = QUAD_BCAST(qv.x, 2); o[9] = QUAD_BCAST(qv.y, 2); o[10] = QUAD_BCAST(qv.z, 2); o[11] = QUAD_BCAST(qv.w, 2);
+    o[12] = QUAD_BCAST(qv.x, 3); o[13] = QUAD_BCAST(qv.y, 3); o[14] = QUAD_BCAST(qv.z, 3); o[15] = QUAD_BCAST(qv.w, 3);
+    return o;
+  };
+#undef QUAD_BCAST
   auto load_tile = [&](int64_t tile, int set) {
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) at[set][ks] = *(const v4i*)(xt + ((tile * 4 + ks) * 64 + lane) * 16);
-    const int4* p = (const int4*)(th_t + (tile * 2 + half) * 16);
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      const int4 kk = p[g];
-      th[set][4 * g] = kk.x; th[set][4 * g + 1] = kk.y; th[set][4 * g + 2] = kk.z; th[set][4 * g + 3] = kk.w;
-    }
+    // the 16 start values of a half-wave: every lane fetches ONE quarter (the quarter its position in its quad names), the
+    // quads then pass the quarters round with DPP moves (spread_th).  Four 16-byte loads per lane instead of one would give
+    // every lane all 16 directly - and cost the CU's single texture-address path 64 cycles per wave and tile instead of 16;
+    // with 13 vector loads per tile that path, not the matrix unit, bounded the kernel (8 waves x 13 x 16 cycles against
+    // 1,024 cycles of MFMAs per tile and SIMD).
+    thq[set] = *(const int4*)(th_t + (tile * 2 + half) * 16 + 4 * (lane & 3));
     pb[set] = pb_t[tile * 2 + half];
   };
   // The ranking of a step's accumulators (see k_knn2_u8) is issued in the gaps between the MFMAs of the NEXT step, across
@@ -563,7 +576,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       if (half == 0 && thr[qb] != (int)0x80000000 && u2[qb] < sent[qb]) {
         // posted with an atomic the compiler does not see (nothing waits for it), picked up by the loads at the top of
         // every tile: a returning atomic here, on one path only, makes the compiler wait with vmcnt(0) in every tile
-        asm volatile("global_atomic_smin %0, %1, off" ::"v"(u2g + (q0 + qb * 32 + l31)), "v"(u2[qb]) : "memory");
+        asm volatile("global_atomic_smin %0, %1, off" ::"v"(u2_mine + qb), "v"(u2[qb]) : "memory");
         s_st[ST_SENT + qb][tid] = u2[qb];
       }
     }
@@ -586,16 +599,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     // the bounds the other splits have posted: fetched in EVERY tile (same number of loads on every path, see below), past
     // the XCD's own L2 (device-scope load), used from the next tile on
 #pragma unroll
-    for (int qb = 0; qb < QB; ++qb) {
-      u2_seen[qb] = u2_next[qb];
-      u2_next[qb] = __hip_atomic_load(u2_mine + qb * 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for (int qb = 0; qb < QB; qb += 2) {
+      u2_seen[qb] = u2_next[qb]; u2_seen[qb + 1] = u2_next[qb + 1];
+      const unsigned long long v = __hip_atomic_load((const unsigned long long*)(u2_mine + qb), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      u2_next[qb] = (int)(unsigned)v; u2_next[qb + 1] = (int)(unsigned)(v >> 32);
     }
     load_tile(tile0 + (t + 1 < n_tiles ? t + 1 : t), pset);
     const int wb_prev = (((t - 1) & 7) << 5) | (4 * half), wb_cur = ((t & 7) << 5) | (4 * half);
+    const v16i th = spread_th(thq[set]);
 #pragma unroll
     for (int qb = 0; qb < QB; ++qb) {
       const v16i& prev = acc[(qb - 1) & 1];                // the very first step ranks the padding values acc[1] starts with
-      acc[qb & 1] = th[set];
+      acc[qb & 1] = th;
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks) {
         acc[qb & 1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(at[set][ks], bq[qb][ks], acc[qb & 1], 0, 0, 0);
@@ -880,7 +895,7 @@ static MatchWs match_ws_carve(char* ws, int64_t n_out, int64_t nt_rows, int64_t 
   w.th = (int*)(ws + off); off += align_up((nt_rows + 32) * 4, 256);
   w.par = (int*)(ws + off); off += align_up((nt_rows + 1) * 4, 256);
   w.qn = (int*)(ws + off); off += align_up(nq_rows * 4, 256);
-  w.u2 = (int*)(ws + off); off += align_up(n_out * 4, 256);                                     // shared candidate thresholds (k_knn2_u8)
+  w.u2 = (int*)(ws + off); off += align_up((n_out + 128) * 4, 256);                             // shared candidate thresholds (whole 128-query wave blocks)
   off += align_up(((n_out + 255) / 256) * 8 + 64, 256);                                        // sfm_match_ratio's scratch may alias here
   w.fix_list = (int*)(ws + off); off += align_up(n_out * 4, 256);
   w.fix_cnt = (int*)(ws + off); off += 256;
@@ -921,7 +936,7 @@ static int match_launch(sfm_ctx* h, int metric, const void* q, int64_t nq_rows, 
     // operations per tile for nothing
     const char* f_env = getenv("SFM_MATCH_FILTER");        // test / tuning knob: "0" off, "1" on
     const bool filter = f_env ? f_env[0] == '1' : filter_rows >= 2048;
-    if (filter || direct) SFM_HIP(h, hipMemsetAsync(w.u2, 0x7F, (size_t)n_out * sizeof(int), h->stream));      // "no bound yet"
+    if (filter || direct) SFM_HIP(h, hipMemsetAsync(w.u2, 0x7F, (size_t)(n_out + 128) * sizeof(int), h->stream));      // "no bound yet"
     sfm_prof_begin(h, SFM_PROF_KNN);
 #define KNN_LAUNCH(KS, QB, F) hipLaunchKernelGGL((k_knn2_u8<KS, QB, F>), dim3(grid), dim3(256), 0, h->stream, q8, nq_rows, w.tf, nt_rows, w.th, w.par, w.qn, nsplit, rps, wg, n_out, w.part, w.u2)
     if (direct) {
