@@ -822,12 +822,28 @@ __global__ __launch_bounds__(256) void k_ratio_count(int64_t nq, const float* __
   __syncthreads();
   if (threadIdx.x == 0) blk_cnt[blockIdx.x] = s_c[0] + s_c[1] + s_c[2] + s_c[3];
 }
-__global__ void k_ratio_scan(int nblk, const int* __restrict__ blk_cnt, int* __restrict__ blk_off,
-                             int64_t* __restrict__ total) {
-  if (blockIdx.x != 0 || threadIdx.x != 0) return;
-  int64_t run = 0;
-  for (int i = 0; i < nblk; ++i) { blk_off[i] = (int)run; run += blk_cnt[i]; }
-  *total = run;
+// exclusive scan of the per-block match counts: ONE workgroup, every thread a contiguous run of blocks (a single thread
+// walking all of them took 42-67 us of dependent loads per call - more than any other kernel of a batched call but the
+// distances)
+__global__ __launch_bounds__(256) void k_ratio_scan(int nblk, const int* __restrict__ blk_cnt, int* __restrict__ blk_off,
+                                                    int64_t* __restrict__ total) {
+  __shared__ int64_t s_sum[256];
+  const int tid = threadIdx.x;
+  const int per = (nblk + 255) / 256;
+  const int beg = tid * per, end = (beg + per) < nblk ? (beg + per) : nblk;
+  int64_t mine = 0;
+  for (int i = beg; i < end; ++i) mine += blk_cnt[i];
+  s_sum[tid] = mine;
+  __syncthreads();
+  for (int o = 1; o < 256; o <<= 1) {                       // inclusive Hillis-Steele scan of the 256 run sums
+    const int64_t v = tid >= o ? s_sum[tid - o] : 0;
+    __syncthreads();
+    s_sum[tid] += v;
+    __syncthreads();
+  }
+  int64_t run = s_sum[tid] - mine;
+  for (int i = beg; i < end; ++i) { blk_off[i] = (int)run; run += blk_cnt[i]; }
+  if (tid == 255) *total = s_sum[255];
 }
 __global__ __launch_bounds__(256) void k_ratio_scatter(int64_t nq, const int* __restrict__ idx1,
                                                        const float* __restrict__ d1, const float* __restrict__ d2,
@@ -1105,7 +1121,7 @@ extern "C" int sfm_match_ratio(sfm_handle h, int64_t nq, const int32_t* idx1, co
   int* blk_cnt = (int*)workspace;
   int* blk_off = blk_cnt + nblk;
   hipLaunchKernelGGL(k_ratio_count, dim3(nblk), dim3(256), 0, h->stream, nq, d1, d2, ratio, blk_cnt);
-  hipLaunchKernelGGL(k_ratio_scan, dim3(1), dim3(64), 0, h->stream, nblk, blk_cnt, blk_off, n_matches);
+  hipLaunchKernelGGL(k_ratio_scan, dim3(1), dim3(256), 0, h->stream, nblk, blk_cnt, blk_off, n_matches);
   hipLaunchKernelGGL(k_ratio_scatter, dim3(nblk), dim3(256), 0, h->stream, nq, idx1, d1, d2, ratio, blk_off,
                      query_idx, train_idx, dist);
   SFM_LAUNCH_CHECK(h, "sfm_match_ratio");
