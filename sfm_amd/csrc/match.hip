@@ -92,7 +92,9 @@ __global__ __launch_bounds__(256) void k_row_norm_u8(const uint8_t* __restrict__
 // bring all three into LDS with direct global->LDS loads (no registers, no ds_write).  Slot nt of every array is
 // the padding row: zero bytes, TH = SENT_TH, PAR = 0.
 __global__ __launch_bounds__(256) void k_train_prep_u8(const uint8_t* __restrict__ x, int64_t n, int dim,
-                                                       uint8_t* __restrict__ xf, int* __restrict__ th, int* __restrict__ par) {
+                                                       uint8_t* __restrict__ xf, int* __restrict__ th, int* __restrict__ par,
+                                                       int* __restrict__ fix_cnt) {
+  if (blockIdx.x == 0 && threadIdx.x == 0) *fix_cnt = 0;    // the re-rank list of this call starts empty (filled by k_merge_splits_u8)
   const int parts = dim >> 4;
   const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
   const int64_t r = t / parts;
@@ -399,12 +401,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(KNN_WAVES, 
 // of a workgroup are independent (they hit the same lines in the CU's L1).  TN_i travels with the tile in register
 // order (16 values per half-wave); TH = TN >> 1 and the parity bit are taken from it in registers.
 __global__ __launch_bounds__(256) void k_train_tile_u8(const uint8_t* __restrict__ x, int64_t n, uint8_t* __restrict__ xt,
-                                                       int* __restrict__ th_t, int* __restrict__ pb_t) {
+                                                       int* __restrict__ th_t, int* __restrict__ pb_t, int* __restrict__ fix_cnt) {
+  __shared__ int s_pb[2];                                  // a workgroup = 256 threads = the 32 rows of ONE tile
+  if (threadIdx.x < 2) s_pb[threadIdx.x] = 0;
+  if (blockIdx.x == 0 && threadIdx.x == 0) *fix_cnt = 0;    // the re-rank list of this call starts empty (filled by k_merge_splits_u8)
+  __syncthreads();
   const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
   const int64_t r = t >> 3;                               // row (up to the end of the last 32-row tile)
   const int gi = (int)(t & 7);                            // 16-byte piece of the row: k-slice gi >> 1, half gi & 1
-  const int64_t n_pad = (n + 31) & ~(int64_t)31;           // whole tiles = whole waves: every shuffle below sees its partners
-  if (r >= n_pad) return;
+  // the grid covers whole tiles (n rounded up to 32 rows): no thread leaves before the barrier below
   uint4 v = make_uint4(0u, 0u, 0u, 0u);
   int s = 0;
   if (r < n) {
@@ -427,11 +432,10 @@ __global__ __launch_bounds__(256) void k_train_tile_u8(const uint8_t* __restrict
   // accumulator register rr of half-wave hh holds row (rr & 3) + 8 (rr >> 2) + 4 hh of the tile
   const int hh = (l31 >> 2) & 1, rr = (l31 & 3) + 4 * (l31 >> 3);
   if (gi == 0) th_t[(tile * 2 + hh) * 16 + rr] = tn >> 1;
-  // parity bits: bit rr of word (tile, hh).  A wave holds 8 rows: rows 8k..8k+3 (hh = 0) and 8k+4..8k+7 (hh = 1) of one
-  // k = rr >> 2; the four rows of a group OR their bits together, lane gi == 0 of the group's first row adds them in.
-  int bit = (gi == 0) ? ((tn & 1) << rr) : 0;
-  bit |= __shfl_xor(bit, 8, 64); bit |= __shfl_xor(bit, 16, 64);                         // rows l31 ^ 1, l31 ^ 2: same hh, same rr >> 2
-  if (gi == 0 && (l31 & 3) == 0) atomicOr(pb_t + tile * 2 + hh, bit);
+  // parity bits: bit rr of word (tile, hh), collected in LDS
+  if (gi == 0 && (tn & 1)) atomicOr(&s_pb[hh], 1 << rr);
+  __syncthreads();
+  if (threadIdx.x < 2) pb_t[tile * 2 + threadIdx.x] = s_pb[threadIdx.x];
 }
 
 template <int QB>
@@ -941,12 +945,9 @@ static int match_launch(sfm_ctx* h, int metric, const void* q, int64_t nq_rows, 
     const char* d_env = getenv("SFM_MATCH_DIRECT");        // test / tuning knob: "0" = the LDS kernel also for the large case
     const bool direct = qb4 && !(d_env && d_env[0] == '0');
     if (direct)
-    {
-      SFM_HIP(h, hipMemsetAsync(w.par, 0, (size_t)(((nt_rows + 31) >> 5) * 2) * sizeof(int), h->stream));      // parity words are OR-ed together
-      hipLaunchKernelGGL(k_train_tile_u8, dim3(cdiv(((nt_rows + 31) & ~(int64_t)31) * 8, 256)), dim3(256), 0, h->stream, t8, nt_rows, w.tf, w.th, w.par);
-    }
+      hipLaunchKernelGGL(k_train_tile_u8, dim3((unsigned)((nt_rows + 31) >> 5)), dim3(256), 0, h->stream, t8, nt_rows, w.tf, w.th, w.par, w.fix_cnt);
     else
-      hipLaunchKernelGGL(k_train_prep_u8, dim3(cdiv((nt_rows + 1) * (dim >> 4), 256)), dim3(256), 0, h->stream, t8, nt_rows, dim, w.tf, w.th, w.par);
+      hipLaunchKernelGGL(k_train_prep_u8, dim3(cdiv((nt_rows + 1) * (dim >> 4), 256)), dim3(256), 0, h->stream, t8, nt_rows, dim, w.tf, w.th, w.par, w.fix_cnt);
     hipLaunchKernelGGL(k_row_norm_u8, dim3(cdiv(nq_rows * (dim >> 4), 256)), dim3(256), 0, h->stream, q8, nq_rows, dim, 0x7F, 0, w.qn);
     // the candidate filter pays once the queries see a few thousand train rows (see k_knn2_u8); below that it is 10
     // operations per tile for nothing
@@ -964,7 +965,6 @@ static int match_launch(sfm_ctx* h, int metric, const void* q, int64_t nq_rows, 
     }
 #undef KNN_LAUNCH
     sfm_prof_end(h, SFM_PROF_KNN);
-    SFM_HIP(h, hipMemsetAsync(w.fix_cnt, 0, sizeof(int), h->stream));
     hipLaunchKernelGGL(k_merge_splits_u8, dim3(cdiv(n_out, 256)), dim3(256), 0, h->stream, n_out, wg ? 8 : nsplit, w.part, idx1, idx2,
                        d1, d2, w.fix_cnt, w.fix_list);
     hipLaunchKernelGGL(k_knn2_u8_rerank, dim3(n_out < 2048 ? (unsigned)n_out : 2048u), dim3(256), 0, h->stream, q8, t8, nt_rows, dim,
