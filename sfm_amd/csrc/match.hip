@@ -9,8 +9,11 @@
 //   TN_i = sum (a+1)^2 - dim,  QN_j = sum (c+1)^2           (all int32, d^2 <= 128*255^2 < 2^23)
 // with dot() from v_mfma_i32_32x32x32_i8 (A = 32 train rows, B = 32 queries: the accumulator puts
 // the query on the lane and 16 train rows in the registers, so the running top-2 of a query never
-// leaves its lane).  Candidates are ranked by ONE int32 key = ((TN_i + 2 dot) << 8) | row-in-chunk,
-// i.e. v_lshl_add_u32 + v_min_i32 + v_med3_i32 per candidate; keys are unpacked every 128 train rows.
+// leaves its lane).  The accumulator starts at TN_i >> 1, so that 2 acc + (TN_i & 1) = d^2 - QN_j; a candidate filter
+// on the accumulators (k_knn2_u8) skips what cannot enter a top-2, the rest is ranked by ONE int32 key
+// = ((d^2 - QN_j) << 8) | row-in-window, i.e. v_lshl_add_u32 + v_min_i32 + v_med3_i32 per candidate; keys are unpacked
+// every 256 train rows.  Two distance kernels: k_knn2_u8 (train rows staged through LDS; batched image pairs, small
+// dims) and k_knn2_u8_direct (one pair with >= 16,384 queries: operands straight from L2, no LDS, no barrier).
 // Ranking rule = the reference's: OpenCV compares the float32 distances sqrtf(d^2), lowest train index first
 // on ties (matcher_oracle.py).  sqrtf is monotone and injective on integers below 2^22, so ranking on the integer
 // d^2 gives the same two neighbours whenever the second-best d^2 is below 2^22 (always, for SIFT descriptors:
