@@ -209,6 +209,35 @@ def test_l2_u8_many_queries_kernel_edges(gpu_ready, nq, nt, kind):
     assert_knn_equal(got, ba_c.knn2_u8(u1, u2))
 
 
+def test_l2_u8_randomised_sizes_and_data(gpu_ready):
+    """A fixed-seed sweep over both uint8 distance kernels and both filter settings (tools/stress_matcher.py runs the
+    long version): random query / train counts on either side of the kernel switch (16,384 queries) and of the filter
+    switch (2,048 train rows), SIFT-like, uniform and duplicate-heavy rows, every row against the C oracle."""
+    import torch
+    from oracle import ba_c
+    from sfm_amd import synth, matcher
+    rng = np.random.default_rng(20260104)
+    for case in range(10):
+        nq = int(rng.integers(16384, 24000)) if case % 2 == 0 else int(rng.integers(1, 16384))
+        nt = int(rng.choice([rng.integers(2, 2048), rng.integers(2048, 12000)]))
+        kind = case % 3
+        if kind == 0:
+            d1, d2 = synth.make_descriptors(nq, nt, seed=case)
+            u1, u2 = d1.astype(np.uint8), d2.astype(np.uint8)
+        elif kind == 1:
+            u1 = rng.integers(0, 256, size=(nq, 128), dtype=np.uint8)
+            u2 = rng.integers(0, 256, size=(nt, 128), dtype=np.uint8)
+        else:
+            base = rng.integers(0, 256, size=(30, 128), dtype=np.uint8)
+            u2 = base[rng.integers(0, 30, size=nt)]
+            u1 = base[rng.integers(0, 30, size=nq)]
+        i1, i2, a, b = matcher.knn2(torch.from_numpy(u1).cuda(), torch.from_numpy(u2).cuda(), "l2")
+        got = (i1.cpu().numpy(), i2.cpu().numpy(), a.cpu().numpy(), b.cpu().numpy())
+        ref = ba_c.knn2_u8(u1, u2)
+        for g, r in zip(got, ref):
+            assert np.array_equal(g, r), (case, nq, nt, kind)
+
+
 # ------------------------------------------------------------------ batched (segmented) matching
 def _image_sets(sizes, seed, kind="sift", dim=128):
     from sfm_amd import synth
