@@ -1,0 +1,84 @@
+#!/usr/bin/env python3
+"""Randomised parity sweep of the bundle-adjustment stages against the C oracle: random camera / point counts (camera
+counts that are not multiples of 8, cameras with very few or very many observations), RAGGED tracks (2 .. 14 cameras per
+point, different for every point), both camera blocks (d = 6, 10), float64 and mixed storage, both camera solvers.
+Per case: linearisation scalars, one damped solve (step vector, ||p||, p^T (H + aI)^-1 p) at two dampings, one trial step.
+Prints one line per case; exits 1 on a mismatch."""
+import os, sys, time
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from oracle import ba_c
+from sfm_amd import synth
+from sfm_amd.ba import GpuBA
+
+def ragged_scene(C, P, rng):
+    sc = synth.make_scene(C, P, obs_per_point=None, seed=int(rng.integers(1 << 30)), noise_px=0.7, pt_sigma=0.03, cam_sigma=0.003)
+    lens = rng.integers(2, min(C, 14) + 1, size=P)
+    if rng.random() < 0.5:                       # a crowd of points seen by the same few cameras, a camera seen by almost none
+        lens[: P // 3] = 2
+    cam_idx, pt_idx = [], []
+    weights = rng.random(C) ** 3 + 1e-3          # very uneven camera popularity
+    weights /= weights.sum()
+    for j in range(P):
+        cams = np.sort(rng.choice(C, size=int(lens[j]), replace=False, p=weights))
+        cam_idx.append(cams); pt_idx.append(np.full(len(cams), j))
+    cam_idx = np.concatenate(cam_idx).astype(np.int64); pt_idx = np.concatenate(pt_idx).astype(np.int64)
+    seen = np.unique(cam_idx)
+    if len(seen) < C:                            # every camera needs observations: give the unseen ones two points each
+        extra_c, extra_p = [], []
+        for c in np.setdiff1d(np.arange(C), seen):
+            for j in rng.choice(P, size=2, replace=False):
+                extra_c.append(c); extra_p.append(j)
+        cam_idx = np.concatenate([cam_idx, extra_c]); pt_idx = np.concatenate([pt_idx, extra_p])
+        key = pt_idx * C + cam_idx
+        _, first = np.unique(key, return_index=True)
+        cam_idx, pt_idx = cam_idx[np.sort(first)], pt_idx[np.sort(first)]
+        o = np.lexsort((cam_idx, pt_idx)); cam_idx, pt_idx = cam_idx[o], pt_idx[o]
+    fx, fy, cx, cy = synth.K_REF
+    Rs = np.stack([synth._rodrigues(sc.cams_true[c, :3]) for c in range(C)])
+    Y = np.einsum("nij,nj->ni", Rs[cam_idx], sc.pts_true[pt_idx]) + sc.cams_true[cam_idx, 3:6]
+    uv = np.stack([fx * Y[:, 0] / Y[:, 2] + cx, fy * Y[:, 1] / Y[:, 2] + cy], axis=1) + rng.normal(0, 0.7, size=(len(cam_idx), 2))
+    return sc, cam_idx, pt_idx, uv.astype(np.float32).astype(np.float64)
+
+def close(a, b, rel):
+    return abs(a - b) <= rel * max(abs(a), abs(b), 1e-300)
+
+rng = np.random.default_rng(int(sys.argv[1]) if len(sys.argv) > 1 else 0)
+n_cases = int(sys.argv[2]) if len(sys.argv) > 2 else 24
+bad = 0
+for c in range(n_cases):
+    C = int(rng.choice([rng.integers(2, 9), rng.integers(9, 40), rng.integers(40, 130)]))
+    P = int(rng.integers(max(20, 2 * C), 4000))
+    d = int(rng.choice([6, 10]))
+    precision = "mixed" if c % 4 == 3 else "fp64"
+    solver = ["auto", "cholesky", "cg"][c % 3]
+    sc, cam_idx, pt_idx, uv = ragged_scene(C, P, rng)
+    cams0 = sc.cams0[:, :d].copy()
+    x0 = np.concatenate([cams0.ravel(), sc.pts0.ravel()])
+    cb = ba_c.CBA(C, P, d, cam_idx, pt_idx, uv, synth.K_REF)
+    rc, rg, ri, rh = cb.linearize(x0)
+    be = GpuBA(cams0, sc.pts0, cam_idx, pt_idx, uv, synth.K_REF, precision=precision, camera_solver=solver)
+    tol = 1e-6 if precision == "mixed" else 1e-8
+    cost, gnorm, ginf, hdiag = be.linearize()
+    ok = close(cost, rc, 1e-10) and close(gnorm, rg, 10 * tol) and close(ginf, ri, 10 * tol) and close(hdiag, rh, 10 * tol)
+    why = "" if ok else "linearize "
+    for alpha in (1e-3 * rg / np.linalg.norm(x0), 0.5 * rh):
+        rpn, rpq = cb.solve(alpha, True)
+        p_ref = cb.step_vector()
+        pn, pq = be.solve(alpha, True)
+        p = np.concatenate([be.view(be.lay.pc_off, C * d).cpu().numpy(), be.view(be.lay.pp_off, P * 3).cpu().numpy()])
+        err = np.linalg.norm(p - p_ref) / np.linalg.norm(p_ref)
+        o2 = err <= 100 * tol and close(pn, rpn, 100 * tol) and close(pq, rpq, 1000 * tol)
+        if not o2: why += f"solve(alpha={alpha:.3g}: err {err:.2e}, pn {pn:.6g}/{rpn:.6g}, pq {pq:.6g}/{rpq:.6g}) "
+        ok = ok and o2
+    scale = 0.8
+    _, (rjs2, rgts, rcost_new, rsnorm, rxnorm) = cb.step(x0, scale)
+    js2, gts, cost_new, snorm, xnorm = be.step(scale)
+    o3 = close(js2, rjs2, 1000 * tol) and close(gts, rgts, 1000 * tol) and close(cost_new, rcost_new, 1e-7) and close(snorm, rsnorm, 100 * tol)
+    if not o3: why += f"step(js2 {js2:.8g}/{rjs2:.8g} gts {gts:.8g}/{rgts:.8g} cost {cost_new:.10g}/{rcost_new:.10g}) "
+    ok = ok and o3
+    bad += not ok
+    print(f"case {c:2d} C={C:3d} P={P:4d} N={len(cam_idx):6d} d={d:2d} {precision:5s} {solver:8s} {'ok' if ok else 'MISMATCH ' + why}", flush=True)
+    del be, cb
+sys.exit(1 if bad else 0)
