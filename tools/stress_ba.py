@@ -81,4 +81,27 @@ for c in range(n_cases):
     bad += not ok
     print(f"case {c:2d} C={C:3d} P={P:4d} N={len(cam_idx):6d} d={d:2d} {precision:5s} {solver:8s} {'ok' if ok else 'MISMATCH ' + why}", flush=True)
     del be, cb
+# the whole trust-region loop (library side, sfm_ba_run_trf) against the dense Python oracle on small ragged scenes:
+# same evaluation counts and status, parameters within 1e-6
+from oracle import ba_oracle as bo
+for c in range(max(4, n_cases // 4)):
+    C = int(rng.integers(3, 14)); P = int(rng.integers(40, 400)); d = int(rng.choice([6, 10]))
+    order = ["aligned", "reference"][c % 2]
+    sc, cam_idx, pt_idx, uv = ragged_scene(C, P, rng)
+    cams0 = sc.cams0[:, :d].copy()
+    cams0[:, :6] += rng.normal(0, 0.004, size=(C, 6))
+    x0 = np.concatenate([cams0.ravel(), sc.pts0.ravel()])
+    uv_eff = bo.effective_uv(uv, cam_idx, order)
+    prob = bo.BAProblem(C, P, d, cam_idx, pt_idx, uv_eff, np.array(synth.K_REF))
+    ref = bo.trf(prob, x0, solver="dense")
+    be = GpuBA(cams0, sc.pts0, cam_idx, pt_idx, uv_eff, synth.K_REF)
+    res = be.run_trf()
+    cams, pts = be.params()
+    x = np.concatenate([cams.ravel(), pts.ravel()])
+    dev = float(np.max(np.abs(x - ref.x) / np.maximum(np.abs(ref.x), 1e-3)))
+    ok = (res.nfev, res.njev, res.status) == (ref.nfev, ref.njev, ref.status) and dev <= 1e-6
+    bad += not ok
+    print(f"trf  {c:2d} C={C:3d} P={P:4d} N={len(cam_idx):6d} d={d:2d} {order:9s} nfev/njev/status {res.nfev}/{res.njev}/{res.status} vs "
+          f"{ref.nfev}/{ref.njev}/{ref.status}  max rel dev {dev:.1e} {'ok' if ok else 'MISMATCH'}", flush=True)
+    del be
 sys.exit(1 if bad else 0)
