@@ -21,6 +21,7 @@
 // lower index must win among them; queries whose second-best d^2 reaches 2^22 are therefore re-ranked on the
 // float32 value over the whole train set by k_knn2_u8_rerank (k_merge_splits_u8 lists them).
 #include "common.h"
+#include "match_plan.h"
 #include <cstdlib>
 #include <vector>
 #include <type_traits>
@@ -42,13 +43,6 @@ struct Cand { float d; int i; };   // distance (already sqrtf'ed / popcount), tr
 // rows against a range of train rows; the host cuts the segments into workgroup-sized pieces (plan_segments) and
 // every workgroup of the distance kernels reads its piece from this record.  wg == nullptr = one segment covering
 // the whole arrays, pieces computed from blockIdx as before.
-struct MatchWG {
-  int64_t q_first, q_end;     // query rows of this workgroup: [q_first, min(q_first + rows per workgroup, q_end))
-  int64_t t_first, t_end;     // train rows of this workgroup's split
-  int64_t t_seg;              // first train row of the segment: train indices are reported relative to it
-  int64_t out_first;          // output row of q_first
-  int32_t split, pad;
-};
 struct MatchSegs {            // device copies of the segment table, for the kernels that work per output row
   const int64_t *q_beg, *t_beg, *t_end, *out_ptr;
   int32_t n_seg;
@@ -881,29 +875,6 @@ __global__ __launch_bounds__(256) void k_f32_to_u8(const float* __restrict__ src
 }
 
 // ------------------------------------------------------------------------------------ host
-static int pick_nsplit(int64_t nt, int64_t n_qblocks) {
-  // Splits of the train set buy parallelism (workgroups = query blocks x splits; the splits of one query block run side
-  // by side and share their candidate threshold, so they do not loosen the filter).  The distance kernel holds two
-  // workgroups per CU: take the split count (<= 8, splits of at least 512 rows) whose LAST round of 512 workgroups is
-  // fullest - at 50k x 50k, 196 query blocks: 5 splits = 1.9 rounds against 8 = 3.06, 10 % of the launch.
-  // SFM_MATCH_NSPLIT overrides (tuning).
-  const char* env = getenv("SFM_MATCH_NSPLIT");
-  int best = 1;
-  if (env) {
-    best = atoi(env);
-    if (best > 8) best = 8;
-    if (best < 1) best = 1;
-  } else {
-    double best_cost = 1e30;
-    for (int ns = 1; ns <= 8; ++ns) {
-      const int64_t wgs = n_qblocks * ns, rounds = (wgs + 511) / 512;
-      const double cost = (double)rounds / ns;             // time ~ rounds x rows per split
-      if (cost < best_cost * 0.98) { best_cost = cost; best = ns; }
-    }
-  }
-  while (best > 1 && nt / best < 512) --best;
-  return best;
-}
 
 // workspace carve (bytes): per-split candidates | train norms | query norms | ratio scratch | re-rank list + counter |
 // (batched only) workgroup records + segment table
@@ -1003,21 +974,7 @@ static int match_check_metric(sfm_ctx* h, int metric, int dim, const char* what)
   return SFM_OK;
 }
 // queries one workgroup of the distance kernel takes
-static int64_t match_qpw(int metric, int dim, int64_t nq, bool batched) {
-  // k_knn2_u8 with four query blocks per wave (512 queries per workgroup: half the train bytes through LDS per pair)
-  // once there are enough queries to fill the chip that way; single segment, dim 128.  SFM_MATCH_QB = 2 / 4 overrides.
-  const char* qb_env = getenv("SFM_MATCH_QB");
-  const bool qb4 = !batched && metric == SFM_METRIC_L2_U8 && dim == 128 && (qb_env ? qb_env[0] == '4' : nq >= 16384);
-  return qb4 ? 512 : 256;
-}
 // rows of train data per split and queries per workgroup of the kernel a metric uses
-static void match_tiling(int metric, int64_t nq, int64_t qpw, int64_t nt, int* nsplit, int64_t* rps) {
-  int ns = pick_nsplit(nt, (nq + qpw - 1) / qpw);
-  int64_t r = (nt + ns - 1) / ns;
-  if (metric == SFM_METRIC_L2_U8) r = align_up(r, 128);
-  *nsplit = (int)((nt + r - 1) / r);
-  *rps = r;
-}
 
 extern "C" int sfm_match_knn2(sfm_handle h, int metric, const void* q, int64_t nq, const void* t, int64_t nt,
                               int dim, int32_t* idx1, int32_t* idx2, float* d1, float* d2, void* workspace,
@@ -1038,27 +995,6 @@ extern "C" int sfm_match_knn2(sfm_handle h, int metric, const void* q, int64_t n
 }
 
 // ---- batched: every image pair of a preprocessing step in one launch
-static void plan_segments(int metric, int dim, int32_t n_seg, const int64_t* q_beg, const int64_t* q_end, const int64_t* t_beg,
-                          const int64_t* t_end, std::vector<MatchWG>* wgs, std::vector<int64_t>* out_ptr) {
-  out_ptr->assign((size_t)n_seg + 1, 0);
-  int64_t all_queries = 0;                           // parallelism comes from all segments together
-  for (int s = 0; s < n_seg; ++s) all_queries += (q_end[s] - q_beg[s] + 255) / 256 * 256;
-  for (int s = 0; s < n_seg; ++s) {
-    const int64_t nq = q_end[s] - q_beg[s], nt = t_end[s] - t_beg[s];
-    (*out_ptr)[s + 1] = (*out_ptr)[s] + nq;
-    if (nq <= 0) continue;
-    int nsplit; int64_t rps;
-    match_tiling(metric, all_queries, 256, nt, &nsplit, &rps);
-    for (int64_t qb = 0; qb < nq; qb += match_qpw(metric, dim, nq, true))
-      for (int sp = 0; sp < nsplit; ++sp) {          // consecutive workgroups = consecutive splits: one XCD per split as in the single-pair launch
-        MatchWG r;
-        r.q_first = q_beg[s] + qb; r.q_end = q_end[s];
-        r.t_first = t_beg[s] + sp * rps; r.t_end = (r.t_first + rps) < t_end[s] ? (r.t_first + rps) : t_end[s];
-        r.t_seg = t_beg[s]; r.out_first = (*out_ptr)[s] + qb; r.split = sp; r.pad = 0;
-        wgs->push_back(r);
-      }
-  }
-}
 
 extern "C" int sfm_match_batched_workspace_bytes(int metric, int32_t n_seg, const int64_t* q_beg_host, const int64_t* q_end_host,
                                                  const int64_t* t_beg_host, const int64_t* t_end_host, int64_t nq_rows,

@@ -337,3 +337,25 @@ def test_oracle_statistics_equal_the_reference_run():
         for k in ("mean_reproj_error", "max_reproj_error", "mean_track_length", "max_track_length"):
             assert st[k] == pytest.approx(float(g[f"{name}_stat_{k}"]), rel=1e-12), (name, k)
         assert st["num_points"] == int(g[f"{name}_stat_num_points"]) and st["num_cameras"] == int(g[f"{name}_stat_num_cameras"])
+
+
+# ------------------------------------------------------------------ native host logic under the sanitizers
+def test_matcher_plan_under_address_and_ub_sanitizers(tmp_path):
+    """sfm_amd/csrc/match_plan.h (how a batch of image pairs is cut into workgroup pieces, how many train splits a
+    launch takes) is plain C++: built here with g++ -fsanitize=address,undefined and driven over random segment tables
+    (empty images, images around the 512-row split limit, large ones).  Found on its first run: a division by zero for a
+    segment without train rows in sfm_match_batched_workspace_bytes, which validates nothing before it plans."""
+    import shutil, subprocess
+    if shutil.which("g++") is None:
+        pytest.skip("no g++")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = tmp_path / "match_plan_check"
+    cmd = ["g++", "-std=c++17", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined",
+           "-fno-omit-frame-pointer", "-I" + os.path.join(root, "sfm_amd", "csrc"),
+           os.path.join(root, "tests", "native", "match_plan_check.cpp"), "-o", str(exe)]
+    build = subprocess.run(cmd, capture_output=True, text=True)
+    assert build.returncode == 0, build.stderr
+    for seed in (1, 2, 3):
+        run = subprocess.run([str(exe), str(seed)], capture_output=True, text=True,
+                             env={k: v for k, v in os.environ.items() if not k.startswith("SFM_MATCH_")})
+        assert run.returncode == 0 and run.stdout.startswith("ok "), (run.stdout, run.stderr[-2000:])
