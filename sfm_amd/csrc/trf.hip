@@ -12,8 +12,7 @@
 #include <cmath>
 #include <vector>
 #include "ba_internal.h"
-
-#define ALPHA_FLOOR_REL 1e-13
+#include "trf_loop.h"      // the state machine itself, backend-agnostic (also built and checked on the CPU)
 
 struct sfm_trf_state_s {
   sfm_ctx* h;
@@ -24,10 +23,9 @@ struct sfm_trf_state_s {
   sfm_reduce_fn reduce;
   void* reduce_user;
   sfm_ba_layout lay;
-  double cost, g_norm, g_inf, hdiag, x_norm, Delta, alpha;
-  int nfev, njev, status /* -1: running */, iteration, n_solves;
+  trf_core::State st;
+  int n_solves;
   long long cg_iters;
-  std::vector<double> trace;
 };
 
 namespace {
@@ -114,53 +112,6 @@ struct Backend {
   }
 };
 
-// scipy common.py:222-248
-void update_tr_radius(double& Delta, double actual, double predicted, double step_norm, bool bound_hit, double* ratio) {
-  double r;
-  if (predicted > 0) r = actual / predicted;
-  else if (predicted == 0 && actual == 0) r = 1;
-  else r = 0;
-  if (r < 0.25) Delta = 0.25 * step_norm;
-  else if (r > 0.75 && bound_hit) Delta *= 2.0;
-  *ratio = r;
-}
-
-// scipy common.py:705-717; 0 = keep going
-int check_termination(double dF, double F, double dx_norm, double x_norm, double ratio, double ftol, double xtol) {
-  const bool f_ok = dF < ftol * F && ratio > 0.25;
-  const bool x_ok = dx_norm < xtol * (xtol + x_norm);
-  if (f_ok && x_ok) return 4;
-  if (f_ok) return 2;
-  if (x_ok) return 3;
-  return 0;
-}
-
-// scipy common.py:57-168 with (H + alpha I) solves in place of the SVD; leaves p(alpha_final)
-// in the workspace.  J has a 7-dof gauge null space: `full_rank` is never taken, alpha_lower starts at 0.
-int solve_tr_more(Backend& be, double g_norm, double Delta, double& alpha, double alpha_floor, double* p_norm_out) {
-  double alpha_upper = g_norm / Delta, alpha_lower = 0.0;
-  if (alpha == 0) alpha = std::fmax(0.001 * alpha_upper, std::sqrt(alpha_lower * alpha_upper));
-  int rc;
-  for (int it = 0; it < 10; ++it) {
-    if (alpha < alpha_lower || alpha > alpha_upper) alpha = std::fmax(0.001 * alpha_upper, std::sqrt(alpha_lower * alpha_upper));
-    const bool on_floor = alpha <= alpha_floor;
-    if (on_floor) alpha = alpha_floor;
-    double p_norm, pq;
-    if ((rc = be.solve(alpha, 1, &p_norm, &pq))) return rc;
-    const double phi = p_norm - Delta;
-    if (on_floor && phi < 0) { *p_norm_out = p_norm; return SFM_OK; }     // interior Gauss-Newton step: p(alpha_floor) is the answer
-    const double phi_prime = -pq / p_norm;
-    if (phi < 0) alpha_upper = alpha;
-    const double ratio = phi / phi_prime;
-    alpha_lower = std::fmax(alpha_lower, alpha - ratio);
-    alpha -= (phi + Delta) * ratio / Delta;
-    if (std::fabs(phi) < 0.01 * Delta) break;
-  }
-  alpha = std::fmax(std::fmax(alpha, alpha_floor), 1e-300);      // the Schur route needs alpha > 0 (SciPy's SVD form does not)
-  double pq;
-  return be.solve(alpha, 0, p_norm_out, &pq);
-}
-
 }  // namespace
 
 extern "C" int sfm_ba_trf_begin(sfm_handle h, sfm_ba_problem p, double* x, const sfm_trf_options* opt,
@@ -175,75 +126,36 @@ extern "C" int sfm_ba_trf_begin(sfm_handle h, sfm_ba_problem p, double* x, const
   const size_t bytes = ((size_t)p->n_cams * p->cam_dim + 3 * (size_t)p->n_pts) * sizeof(double);
   if (hipMalloc((void**)&s->x_new, bytes) != hipSuccess) { delete s; return sfm_fail(h, SFM_ERR_HIP, "sfm_ba_trf_begin", "hipMalloc"); }
   Backend be{s};
-  int rc = be.linearize(&s->cost, &s->g_norm, &s->g_inf, &s->hdiag);
-  if (!rc) rc = be.x_norm(&s->x_norm);
-  if (rc) { (void)hipFree(s->x_new); delete s; return rc; }
-  s->nfev = 1; s->njev = 1;
-  s->Delta = s->x_norm > 0 ? s->x_norm : 1.0;
-  s->alpha = 0.0;
-  s->status = -1;
-  s->iteration = 0;
   s->n_solves = 0;
+  const int rc = trf_core::begin(be, s->st);
+  if (rc) { (void)hipFree(s->x_new); delete s; return rc; }
   *out = s;
   return SFM_OK;
 }
 
 extern "C" int sfm_ba_trf_outer(sfm_trf_state s, int* more) {
   if (!s || !more) return SFM_ERR_ARG;
-  *more = 0;
   const sfm_trf_options& o = s->opt;
-  if (o.max_outer >= 0 && s->iteration >= o.max_outer) return SFM_OK;
-  if (s->g_inf < o.gtol && o.check_tolerances && s->status < 0) s->status = 1;
-  if (s->status >= 0 || s->nfev == o.max_nfev) return SFM_OK;
+  const trf_core::Options co = {o.ftol, o.xtol, o.gtol, o.max_nfev, o.max_outer, o.check_tolerances};
   Backend be{s};
-  double actual = -1.0, cost_new = s->cost, xnew_norm = s->x_norm;
-  int rc;
-  while (actual <= 0 && s->nfev < o.max_nfev) {
-    double p_norm;
-    if ((rc = solve_tr_more(be, s->g_norm, s->Delta, s->alpha, ALPHA_FLOOR_REL * s->hdiag, &p_norm))) return rc;
-    double js2, gts, step_norm;
-    if ((rc = be.step(s->Delta / p_norm, &js2, &gts, &cost_new, &step_norm, &xnew_norm))) return rc;
-    const double predicted = -(0.5 * js2 + gts);
-    s->nfev++;
-    if (!std::isfinite(cost_new)) { s->Delta = 0.25 * step_norm; continue; }
-    actual = s->cost - cost_new;
-    double Delta_new = s->Delta, ratio;
-    update_tr_radius(Delta_new, actual, predicted, step_norm, step_norm > 0.95 * s->Delta, &ratio);
-    s->trace.push_back(s->alpha); s->trace.push_back(s->Delta); s->trace.push_back(step_norm); s->trace.push_back(actual > 0 ? 1.0 : 0.0);
-    if (o.check_tolerances) {
-      const int t = check_termination(actual, s->cost, step_norm, s->x_norm, ratio, o.ftol, o.xtol);
-      if (t) { s->status = t; break; }
-    }
-    s->alpha *= s->Delta / Delta_new;
-    s->Delta = Delta_new;
-  }
-  if (actual > 0) {
-    if ((rc = be.accept())) return rc;
-    s->x_norm = xnew_norm;
-    s->cost = cost_new;
-    double c_unused;
-    if ((rc = be.linearize(&c_unused, &s->g_norm, &s->g_inf, &s->hdiag))) return rc;
-    s->njev++;
-  }
-  s->iteration++;
-  *more = 1;
-  return SFM_OK;
+  return trf_core::outer(be, s->st, co, more);
 }
 
 extern "C" int sfm_ba_trf_result(sfm_trf_state s, sfm_trf_result* out) {
   if (!s || !out) return SFM_ERR_ARG;
-  out->cost = s->cost; out->optimality = s->g_inf;
-  out->nfev = s->nfev; out->njev = s->njev; out->status = s->status < 0 ? 0 : s->status;
-  out->n_solves = s->n_solves; out->n_outer = s->iteration; out->cg_iters = (int32_t)(s->cg_iters > 0x7fffffff ? 0x7fffffff : s->cg_iters);
+  out->cost = s->st.cost; out->optimality = s->st.g_inf;
+  out->nfev = s->st.nfev; out->njev = s->st.njev; out->status = s->st.status < 0 ? 0 : s->st.status;
+  out->n_solves = s->n_solves; out->n_outer = s->st.iteration; out->cg_iters = (int32_t)(s->cg_iters > 0x7fffffff ? 0x7fffffff : s->cg_iters);
   return SFM_OK;
 }
 
 extern "C" int sfm_ba_trf_trace(sfm_trf_state s, double* out_host, int32_t capacity_trials) {
   if (!s) return 0;
-  const int n = (int)(s->trace.size() / 4);
+  const std::vector<double>& trace = s->st.trace;
+  const int n = (int)(trace.size() / 4);
   if (out_host)
     for (int i = 0; i < n && i < capacity_trials; ++i)
-      for (int q = 0; q < 4; ++q) out_host[4 * i + q] = s->trace[4 * (size_t)i + q];
+      for (int q = 0; q < 4; ++q) out_host[4 * i + q] = trace[4 * (size_t)i + q];
   return n;
 }
 

@@ -359,3 +359,76 @@ def test_matcher_plan_under_address_and_ub_sanitizers(tmp_path):
         run = subprocess.run([str(exe), str(seed)], capture_output=True, text=True,
                              env={k: v for k, v in os.environ.items() if not k.startswith("SFM_MATCH_")})
         assert run.returncode == 0 and run.stdout.startswith("ok "), (run.stdout, run.stderr[-2000:])
+
+
+class _DenseFitBackend:
+    """The problem of tests/native/trf_loop_check.cpp in NumPy, behind the backend protocol of sfm_amd/trf.py."""
+
+    def __init__(self, x0):
+        self.t = 0.25 * np.arange(16)
+        truth = np.array([2.0, 0.7, 1.5, 0.1, 0.3])
+        self.y = (truth[0] * np.exp(-truth[1] * self.t) + truth[2] * np.exp(-truth[3] * self.t) + truth[4]
+                  + 0.01 * np.sin(3.7 * np.arange(16)))
+        self.x = np.array(x0, dtype=np.float64)
+
+    def _f(self, v):
+        return v[0] * np.exp(-v[1] * self.t) + v[2] * np.exp(-v[3] * self.t) + v[4] - self.y
+
+    def linearize(self):
+        x, t = self.x, self.t
+        self.f = self._f(x)
+        e1, e3 = np.exp(-x[1] * t), np.exp(-x[3] * t)
+        self.J = np.stack([e1, -x[0] * t * e1, e3, -x[2] * t * e3, np.ones_like(t)], axis=1)
+        self.g = self.J.T @ self.f
+        self.H = self.J.T @ self.J
+        return 0.5 * float(self.f @ self.f), float(np.linalg.norm(self.g)), float(np.abs(self.g).max()), float(np.diag(self.H).max())
+
+    def solve(self, alpha, want_q):
+        A = self.H + alpha * np.eye(5)
+        self.p = np.linalg.solve(A, -self.g)
+        pq = float(self.p @ np.linalg.solve(A, self.p)) if want_q else 0.0
+        return float(np.linalg.norm(self.p)), pq
+
+    def step(self, scale):
+        s = scale * self.p
+        self.xn = self.x + s
+        fn = self._f(self.xn)
+        js = self.J @ s
+        return float(js @ js), float(self.g @ s), 0.5 * float(fn @ fn), float(np.linalg.norm(s)), float(np.linalg.norm(self.xn))
+
+    def x_norm(self):
+        return float(np.linalg.norm(self.x))
+
+    def accept(self):
+        self.x = self.xn
+
+
+@pytest.mark.parametrize("ftol,xtol,max_nfev,x0", [(1e-8, 1e-8, 100, (1.0, 1.0, 1.0, 0.5, 0.0)),
+                                                   (1e-4, 1e-4, 100, (3.0, 0.2, 0.5, 0.4, 1.0)),
+                                                   (1e-10, 1e-10, 12, (1.0, 2.0, 3.0, 0.01, -1.0)),
+                                                   (1e-6, 1e-6, 100, (2.2, 0.6, 1.2, 0.2, 0.2))])
+def test_native_trf_loop_equals_python_loop_under_sanitizers(tmp_path, ftol, xtol, max_nfev, x0):
+    """The trust-region state machine the library runs (sfm_amd/csrc/trf_loop.h, instantiated by trf.hip with the device
+    backend) built on its own with g++ -fsanitize=address,undefined over a small dense problem, against sfm_amd/trf.py
+    (the loop the multi-rank CPU tests and the oracle comparisons drive) on the same problem in NumPy: same evaluation
+    counts, termination status and number of trials, same parameters.  The GPU suite holds the two loops together on the
+    real backend (test_c_loop_equals_python_loop); this is the part of that which needs no GPU."""
+    import shutil
+    from sfm_amd.trf import trf
+    if shutil.which("g++") is None:
+        pytest.skip("no g++")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = tmp_path / "trf_loop_check"
+    build = subprocess.run(["g++", "-std=c++17", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined",
+                            "-I" + os.path.join(root, "sfm_amd", "csrc"), os.path.join(root, "tests", "native", "trf_loop_check.cpp"),
+                            "-o", str(exe)], capture_output=True, text=True)
+    assert build.returncode == 0, build.stderr
+    run = subprocess.run([str(exe), repr(ftol), repr(xtol), str(max_nfev)] + [repr(v) for v in x0], capture_output=True, text=True)
+    assert run.returncode == 0, (run.stdout, run.stderr[-2000:])
+    vals = run.stdout.split()
+    nfev, njev, status, cost, x, n_trials = int(vals[0]), int(vals[1]), int(vals[2]), float(vals[3]), np.array(vals[4:9], float), int(vals[9])
+    be = _DenseFitBackend(x0)
+    ref = trf(be, ftol=ftol, xtol=xtol, max_nfev=max_nfev)
+    assert (nfev, njev, status, n_trials) == (ref.nfev, ref.njev, ref.status, len(ref.trace))
+    assert cost == pytest.approx(ref.cost, rel=1e-9)
+    assert np.allclose(x, be.x, rtol=1e-8, atol=1e-10)
