@@ -19,6 +19,7 @@
 //   S | r  [(n+1)][n] reduced camera system with its right-hand side as a bordered row
 // Observations of one point (a track) are contiguous; cameras are reached through cam_obs.
 #include "ba_internal.h"
+#include <type_traits>
 #include <cmath>
 
 typedef double v4d __attribute__((ext_vector_type(4)));
@@ -50,6 +51,7 @@ Lay ba_layout(int64_t C, int64_t P, int64_t N, int64_t D, int64_t n_items, int64
   L.v = take(P * 3);
   L.tmp3 = take(N * 3);
   L.G = take(N * 3 * D);                           // always float64 (see the header of this file)
+  L.eobs = take(N * 3);                 // e_j = M g_pj copied per observation (read with the G row by the diagonal Schur items)
   L.red_lin = take(2 * n + 2);
   L.gmax = take(2);
   L.red_S = take(n * n + n);
@@ -512,17 +514,23 @@ __global__ void k_point_factor(int P, double alpha, const double* __restrict__ C
 template <int D, typename T, typename TG, int GS>
 __global__ __launch_bounds__(256) void k_build_G(int64_t N, const int* __restrict__ pt_idx,
                                                  const T* __restrict__ recA, const T* __restrict__ recB,
-                                                 const double* __restrict__ Linv, TG* __restrict__ G) {
+                                                 const double* __restrict__ Linv, TG* __restrict__ G,
+                                                 const double* __restrict__ e, double* __restrict__ eobs) {
   const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
   const int64_t k = t >> 4;
   const int a = (int)(t & 15);
-  if (k >= N || a >= D) return;
+  if (k >= N || a >= D + 3) return;
+  // lanes a < D: one column of G each.  Lanes D .. D+2 copy e_j next to the observation (k_schur_items, diagonal items):
+  // the same loads with other addresses, so that the wave does not run two dependent-load chains one after the other
+  const bool col = a < D;
+  const int64_t pj = pt_idx[k];
   const T* r = recA + (size_t)k * (2 * D);
-  const double* M = Linv + (size_t)pt_idx[k] * 6;
+  const double* M = Linv + (size_t)pj * 6;
   const T* jp = recB + (size_t)k * 8;
   const double j0 = jp[0], j1 = jp[1], j2 = jp[2], j3 = jp[3], j4 = jp[4], j5 = jp[5];
   const double m00 = M[0], m10 = M[1], m11 = M[2], m20 = M[3], m21 = M[4], m22 = M[5];
-  const double c0 = r[a], c1 = r[D + a];
+  const double c0 = col ? (double)r[a] : e[pj * 3 + (a - D)], c1 = col ? (double)r[D + a] : 0.0;
+  if (!col) { eobs[k * 3 + (a - D)] = c0; return; }
   TG* g = G + (size_t)k * GS + a;
   g[0] = (TG)(c0 * (j0 * m00) + c1 * (j3 * m00));
   g[D] = (TG)(c0 * (j0 * m10 + j1 * m11) + c1 * (j3 * m10 + j4 * m11));
@@ -538,25 +546,36 @@ __global__ __launch_bounds__(256) void k_build_G(int64_t N, const int* __restric
 // 16 gathers of 8 pairs are in flight together.  k_schur_assemble then sums the items of each block in
 // order (bitwise reproducible), adds B_c on the diagonal and writes the block and its mirror.
 template <int D, typename T, int GS>
-__global__ __launch_bounds__(256) void k_schur_items(const int* __restrict__ xcd_ptr, const int* __restrict__ xcd_items,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) void k_schur_items(const int* __restrict__ xcd_ptr, const int* __restrict__ xcd_items,
                                                      const int* __restrict__ item_beg,
                                                      const int* __restrict__ item_end,
                                                      const int* __restrict__ pair_k, const int* __restrict__ pair_k2,
-                                                     const T* __restrict__ G, double* __restrict__ part) {
+                                                     const T* __restrict__ G, double* __restrict__ part,
+                                                     const int* __restrict__ cam_idx,
+                                                     const int* __restrict__ item_ptr, const int* __restrict__ cch_ptr, int n_cams,
+                                                     const double* __restrict__ eobs, double* __restrict__ cch_part) {
   // Gathers are latency-bound (about 5 us under load), so what counts is useful bytes in flight per register:
   // a G block is BB bytes = CH 16-byte chunks, one lane fetches one chunk (global_load_dwordx4) and one
   // instruction fetches BPL whole blocks (float64 D = 10: 4 blocks on 60 lanes, D = 6: 7 on 63; float32 D = 10:
   // 8 blocks = 8 full 128-byte lines on 64 lanes, D = 6: 12 on 60) - at least twice the bytes per VGPR of a
   // one-element-per-lane gather that only 30 of 64 lanes take part in.  The blocks then pass through a
   // wave-private LDS slab to reach the MFMA operand layout (lane = (row, m)), widened to float64 there.
+  //
+  // Items of a DIAGONAL block (c, c) hold only self-pairs (k, k): one gather serves both operands, and the product's
+  // spare column D carries the right-hand side with it - B operand column D = e_j (the point's M g_p), so the same MFMA
+  // leaves sum_k G_k e_j in accumulator column D.  It goes to the chunk partials k_cam_reduce_final turns into
+  // r_c = g_c - sum (item piece i of block (c, c) <-> observation chunk i of camera c: both cut the camera's list by 256),
+  // which spares the separate pass over G for the right-hand side (72 us, a gather by camera, per damped solve).
   typedef int chunk_t __attribute__((ext_vector_type(4)));
   constexpr int BB = GS * (int)sizeof(T);      // bytes per G block
   static_assert(BB % 16 == 0, "a G block must be a whole number of 16-byte chunks");
+  static_assert(D < 16, "column D of the 16 x 16 product is the right-hand side");
   constexpr int CH = BB / 16;                  // 16-byte chunks per block
   constexpr int BPL = 64 / CH;                 // blocks per load instruction
   constexpr int U = (64 + BPL - 1) / BPL < 8 ? (64 + BPL - 1) / BPL : 8;   // load instructions in flight per operand (16 costs occupancy: measured slower)
   constexpr int PB = U * BPL;                  // pairs per batch
   __shared__ __attribute__((aligned(16))) char s_stage[4][2][BPL * BB];
+  __shared__ double s_e[4][64][3];             // diagonal items: e_j of the 64 pairs whose ids the wave holds
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   // workgroup b serves item group b % 8 (block rows c = b % 8 mod 8): with the round-robin XCD placement one
   // XCD sees every item of a camera's block row, so that camera's G blocks (1.2 MB at 5,000 observations) are
@@ -575,47 +594,77 @@ __global__ __launch_bounds__(256) void k_schur_items(const int* __restrict__ xcd
   char* sB = s_stage[w][1];
   const char* Gb = (const char*)G;
   v4d acc = {0.0, 0.0, 0.0, 0.0};
-  for (int base = beg; base < end; base += 64) {
-    const int idx = base + lane;
-    const int kk = idx < end ? pair_k[idx] : 0;
-    const int kk2 = idx < end ? pair_k2[idx] : 0;
-    const int cnt = (end - base) < 64 ? (end - base) : 64;
-    for (int u0 = 0; u0 < cnt; u0 += PB) {
-      chunk_t ra[U], rb[U];
-#pragma unroll
-      for (int t = 0; t < U; ++t) {
-        const int p = u0 + t * BPL + lb;                  // pair this lane fetches a chunk of
-        const int k = __shfl(kk, p & 63, 64), k2 = __shfl(kk2, p & 63, 64);
-        const bool ok = loader && p < cnt;
-        ra[t] = ok ? *(const chunk_t*)(Gb + (size_t)k * BB + 16 * lc) : (chunk_t){0, 0, 0, 0};
-        rb[t] = ok ? *(const chunk_t*)(Gb + (size_t)k2 * BB + 16 * lc) : (chunk_t){0, 0, 0, 0};
+  const int k_first = __builtin_amdgcn_readfirstlane(pair_k[beg]), k2_first = __builtin_amdgcn_readfirstlane(pair_k2[beg]);
+  const bool diag = k_first == k2_first;                  // wave-uniform: a block with one self-pair has nothing else
+  const bool e_lane = (row == D) && (m < 3);              // B operand column D
+  // two instantiations of the item loop (the off-diagonal one is the kernel as it was: nothing of the diagonal path in it)
+  auto run = [&](auto diag_c) __attribute__((always_inline)) {
+    constexpr bool DIAG = decltype(diag_c)::value;
+    for (int base = beg; base < end; base += 64) {
+      const int idx = base + lane;
+      const int kk = idx < end ? pair_k[idx] : 0;
+      const int kk2 = DIAG ? kk : (idx < end ? pair_k2[idx] : 0);
+      const int cnt = (end - base) < 64 ? (end - base) : 64;
+      if (DIAG) {
+        // e_j of this lane's pair (the per-observation copy k_build_G leaves) -> LDS, in flight together with the G loads
+        // of the batch below
+        const double* ej = eobs + (size_t)kk * 3;
+        const double e0 = ej[0], e1 = ej[1], e2 = ej[2];
+        s_e[w][lane][0] = e0; s_e[w][lane][1] = e1; s_e[w][lane][2] = e2;
       }
+      for (int u0 = 0; u0 < cnt; u0 += PB) {
+        chunk_t ra[U], rb[U];
 #pragma unroll
-      for (int t = 0; t < U; ++t) {
-        if (u0 + t * BPL >= cnt) break;                   // wave-uniform
-        if (loader) {
-          *(chunk_t*)(sA + lb * BB + 16 * lc) = ra[t];
-          *(chunk_t*)(sB + lb * BB + 16 * lc) = rb[t];
+        for (int t = 0; t < U; ++t) {
+          const int p = u0 + t * BPL + lb;                  // pair this lane fetches a chunk of
+          const int k = __shfl(kk, p & 63, 64);
+          const bool ok = loader && p < cnt;
+          ra[t] = ok ? *(const chunk_t*)(Gb + (size_t)k * BB + 16 * lc) : (chunk_t){0, 0, 0, 0};
+          if (!DIAG) {
+            const int k2 = __shfl(kk2, p & 63, 64);
+            rb[t] = ok ? *(const chunk_t*)(Gb + (size_t)k2 * BB + 16 * lc) : (chunk_t){0, 0, 0, 0};
+          }
         }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 #pragma unroll
-        for (int bb = 0; bb < BPL; ++bb) {
-          if (u0 + t * BPL + bb >= cnt) break;            // wave-uniform
-          const double a = valid ? (double)((const T*)sA)[bb * GS + off] : 0.0;
-          const double b = valid ? (double)((const T*)sB)[bb * GS + off] : 0.0;
-          acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
+        for (int t = 0; t < U; ++t) {
+          if (u0 + t * BPL >= cnt) break;                   // wave-uniform
+          if (loader) {
+            *(chunk_t*)(sA + lb * BB + 16 * lc) = ra[t];
+            if (!DIAG) *(chunk_t*)(sB + lb * BB + 16 * lc) = rb[t];
+          }
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+          for (int bb = 0; bb < BPL; ++bb) {
+            if (u0 + t * BPL + bb >= cnt) break;            // wave-uniform
+            const double a = valid ? (double)((const T*)sA)[bb * GS + off] : 0.0;
+            double b;
+            if (DIAG) b = valid ? a : (e_lane ? s_e[w][u0 + t * BPL + bb][m] : 0.0);
+            else b = valid ? (double)((const T*)sB)[bb * GS + off] : 0.0;
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
+          }
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");     // the slab is rewritten by the next t
         }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");     // the slab is rewritten by the next t
       }
     }
-  }
+  };
+  if (diag) run(std::true_type{}); else run(std::false_type{});
   const int col = lane & 15;
   if (col < D) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int rr = (lane >> 4) + 4 * i;
       if (rr < D) part[(size_t)it * (D * D) + rr * D + col] = acc[i];
+    }
+  } else if (diag && col == D) {
+    // piece number of this item inside block (c, c) = chunk number inside camera c
+    const int c = cam_idx[k_first];
+    const int64_t blk = (int64_t)c * n_cams - (int64_t)c * (c - 1) / 2;
+    const int ch = cch_ptr[c] + (it - item_ptr[blk]);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int rr = (lane >> 4) + 4 * i;
+      if (rr < D) cch_part[(size_t)ch * 16 + rr] = acc[i];
     }
   }
 }
@@ -1078,20 +1127,19 @@ extern "C" int sfm_ba_schur_build(sfm_handle h, sfm_ba_problem p, double alpha) 
                      WS(L, Linv), WS(L, e));
   DISPATCH_DT(D, p->precision, {
     hipLaunchKernelGGL((k_build_G<DD, TT, double, GG>), dim3(cdiv(N * 16, 256)), dim3(256), 0, h->stream, N, p->pt_idx, WST(L, recA),
-                       WST(L, recB), WS(L, Linv), WS(L, G));
+                       WST(L, recB), WS(L, Linv), WS(L, G), WS(L, e), WS(L, eobs));
     sfm_prof_end(h, SFM_PROF_BUILD_G);
     sfm_prof_begin(h, SFM_PROF_SCHUR);
     if (p->n_items > 0) { // 8 groups x ceil(largest group / 4) workgroups
       sfm_prof_begin(h, SFM_PROF_SCHUR_ITEMS);
       hipLaunchKernelGGL((k_schur_items<DD, double, GG>), dim3(8 * cdiv(p->xcd_max_items, 4)), dim3(256), 0, h->stream,
-                         p->xcd_ptr, p->xcd_items, p->item_beg, p->item_end, p->pair_k, p->pair_k2, WS(L, G), WS(L, sch_part));
+                         p->xcd_ptr, p->xcd_items, p->item_beg, p->item_end, p->pair_k, p->pair_k2, WS(L, G), WS(L, sch_part),
+                         p->cam_idx, p->item_ptr, p->cch_ptr, C, WS(L, eobs), WS(L, cch_part));
       sfm_prof_end(h, SFM_PROF_SCHUR_ITEMS);
     }
     hipLaunchKernelGGL(k_schur_assemble<DD>, dim3(C, cdiv(C, 2)), dim3(256), 0, h->stream, C, p->item_ptr,
                        WS(L, sch_part), WS(L, B), WS(L, red_S));
-    if (p->n_cchunks > 0)
-      hipLaunchKernelGGL((k_cam_reduce_chunks<DD, double, GG>), dim3((unsigned)p->n_cchunks), dim3(256), 0, h->stream, p->cch_beg,
-                         p->cch_end, p->cam_obs, p->pt_idx, WS(L, G), WS(L, e), WS(L, cch_part));
+    // the chunk partials of sum_k G_k e_j came out of the diagonal-block items above
     hipLaunchKernelGGL(k_cam_reduce_final<DD>, dim3(cdiv(n, 256)), dim3(256), 0, h->stream, C, p->cch_ptr,
                        WS(L, cch_part), WS(L, gc), WS(L, red_S) + (size_t)n * n);
     sfm_prof_end(h, SFM_PROF_SCHUR);
@@ -1730,7 +1778,7 @@ extern "C" int sfm_ba_solve_pcg(sfm_handle h, sfm_ba_problem p, double alpha, in
   hipLaunchKernelGGL(k_point_factor, dim3(cdiv(P, 256)), dim3(256), 0, h->stream, P, alpha, WS(L, Cp), WS(L, gp), WS(L, Linv), WS(L, e));
   DISPATCH_DT(D, p->precision, {
     hipLaunchKernelGGL((k_build_G<DD, TT, double, GG>), dim3(cdiv(N * 16, 256)), dim3(256), 0, h->stream, N, p->pt_idx, WST(L, recA),
-                       WST(L, recB), WS(L, Linv), WS(L, G));
+                       WST(L, recB), WS(L, Linv), WS(L, G), WS(L, e), WS(L, eobs));
     sfm_prof_end(h, SFM_PROF_BUILD_G);
     sfm_prof_begin(h, SFM_PROF_SCHUR);
     if (p->n_cchunks > 0) {

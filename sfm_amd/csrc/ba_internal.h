@@ -3,7 +3,7 @@
 #include "dense.h"
 
 struct Lay {   // workspace offsets in doubles (regions holding float32 in mixed precision are sized in doubles too)
-  int64_t recA, recB, campre, campre2, B, gc, Cp, gp, Linv, e, v, tmp3, G, red_lin, gmax, red_S, red_q,
+  int64_t recA, recB, campre, campre2, B, gc, Cp, gp, Linv, e, v, tmp3, G, eobs, red_lin, gmax, red_S, red_q,
       red_step, pc, pp, y, tvec, scalars, part_obs, part_pt, part_x, cost_reg, regrec, dense, sch_part, cch_part, cbl_part,
       cg_r, cg_z, cg_p, cg_Ap, cg_M, cg_Minv, cg_scal, total;
   int64_t nblk_obs, nblk_pt;
