@@ -19,6 +19,7 @@
 //   S | r  [(n+1)][n] reduced camera system with its right-hand side as a bordered row
 // Observations of one point (a track) are contiguous; cameras are reached through cam_obs.
 #include "ba_internal.h"
+#include <cstdlib>
 #include <type_traits>
 #include <cmath>
 
@@ -1395,8 +1396,12 @@ __global__ __launch_bounds__(256) void k_cgs_iter(int n, int it, double rtol2, c
 static int cgs_solve(sfm_ctx* h, int n, const double* St, const double* rhs_t, double* x_t, double* vec, double* scal,
                      double rtol, int* iters_out, int* status) {
   // (column chunks per thread, rows per workgroup): 128 registers of prefetched matrix per thread in the two larger shapes
-  const int shape = n <= 1024 ? 0 : (n <= 2048 ? 1 : 2);
-  const int rows = shape == 2 ? 4 : 8;
+  // four rows per workgroup: at n = 2000 that is 512 workgroups (two per CU) - 8 rows / 256 workgroups measured 6 % slower per
+  // iteration, 2 rows / 1,024 workgroups 9 % slower (twice the redundant vector work).  SFM_CGS_ROWS=8 restores the old shapes.
+  const char* cg_env = getenv("SFM_CGS_ROWS");
+  const bool rows8 = cg_env && cg_env[0] == '8';
+  const int shape = n <= 1024 ? (rows8 ? 0 : 5) : (n <= 2048 ? (rows8 ? 1 : 3) : 2);
+  const int rows = (shape == 0 || shape == 1) ? 8 : 4;
   const int per_xcd_wg = (int)cdiv(cdiv(n, 8), rows);
   const unsigned grid = 8u * (unsigned)per_xcd_wg;
   hipLaunchKernelGGL(k_cgs_init, dim3(1), dim3(256), 0, h->stream, n, rhs_t, x_t, vec, vec + n, scal);
@@ -1408,6 +1413,8 @@ static int cgs_solve(sfm_ctx* h, int n, const double* St, const double* rhs_t, d
     for (int b = 0; b < batch; ++b, ++it)
       if (shape == 0) hipLaunchKernelGGL((k_cgs_iter<2, 8>), dim3(grid), dim3(256), 0, h->stream, n, it, rtol2, St, vec, x_t, scal);
       else if (shape == 1) hipLaunchKernelGGL((k_cgs_iter<4, 8>), dim3(grid), dim3(256), 0, h->stream, n, it, rtol2, St, vec, x_t, scal);
+      else if (shape == 3) hipLaunchKernelGGL((k_cgs_iter<4, 4>), dim3(grid), dim3(256), 0, h->stream, n, it, rtol2, St, vec, x_t, scal);
+      else if (shape == 5) hipLaunchKernelGGL((k_cgs_iter<2, 4>), dim3(grid), dim3(256), 0, h->stream, n, it, rtol2, St, vec, x_t, scal);
       else hipLaunchKernelGGL((k_cgs_iter<8, 4>), dim3(grid), dim3(256), 0, h->stream, n, it, rtol2, St, vec, x_t, scal);
     SFM_HIP(h, hipMemcpyAsync(h->pinned, scal, 8 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
     SFM_HIP(h, hipStreamSynchronize(h->stream));
