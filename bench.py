@@ -209,8 +209,10 @@ def main():
                               else "256-column strips + rank-256 trailing updates"))
     roofs = cam_roofs + [
         roof("k_schur_items (S blocks = -sum G_k G_k2^T per camera pair, f64 MFMA)", "hbm",
-             2.0 * main["n_pairs"] * 3 * d * 8, 1e9, HBM_PEAK_GBS, "GB/s", "schur_items", "k_schur_items",
-             note="a gather: `achieved` counts the G blocks pulled per launch (2 x 240 B per camera pair, every block ~11 times), "
+             (2.0 * main["n_pairs"] - main["n_obs_local"]) * 3 * d * 8 + main["n_obs_local"] * 24.0, 1e9, HBM_PEAK_GBS, "GB/s",
+             "schur_items", "k_schur_items",
+             note="a gather: `achieved` counts the G blocks pulled per launch (2 x 240 B per camera pair - one block and the 24 B "
+                  "of e_j for the self-pairs of the diagonal blocks, whose accumulator column 10 is the right-hand side -, every block ~10 times), "
                   "`traffic` what leaves the L2s for the Infinity Cache / HBM; the unique data is %.0f MB of G + %.0f MB of pair "
                   "indices - see unique_bytes / refetch" % (main["n_obs_local"] * 3 * d * 8 / 1e6, main["n_pairs"] * 8 / 1e6)),
         roof("k_lin_obs (residual + 2x(%d+3) Jacobian + Huber scaling)" % d, "hbm", float(bytes_per_obs) * main["n_obs_local"],
