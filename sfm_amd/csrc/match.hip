@@ -13,7 +13,7 @@
 // on the accumulators (k_knn2_u8) skips what cannot enter a top-2, the rest is ranked by ONE int32 key
 // = ((d^2 - QN_j) << 8) | row-in-window, i.e. v_lshl_add_u32 + v_min_i32 + v_med3_i32 per candidate; keys are unpacked
 // every 256 train rows.  Two distance kernels: k_knn2_u8 (train rows staged through LDS; batched image pairs, small
-// dims) and k_knn2_u8_direct (one pair with >= 16,384 queries: operands straight from L2, no LDS, no barrier).
+// dims) and k_knn2_u8_direct (one pair with >= 12,288 queries: operands straight from L2, no LDS, no barrier).
 // Ranking rule = the reference's: OpenCV compares the float32 distances sqrtf(d^2), lowest train index first
 // on ties (matcher_oracle.py).  sqrtf is monotone and injective on integers below 2^22, so ranking on the integer
 // d^2 gives the same two neighbours whenever the second-best d^2 is below 2^22 (always, for SIFT descriptors:

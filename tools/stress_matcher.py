@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Randomised parity sweep of the uint8 kNN kernels against the C oracle (every row): sizes across the kernel switch
-(16,384 queries), the filter switch (2,048 train rows), ragged tiles / windows / splits, SIFT-like, uniform, duplicate-heavy
+(12,288 queries), the filter switch (2,048 train rows), ragged tiles / windows / splits, SIFT-like, uniform, duplicate-heavy
 and far-apart (float32 re-ranking) data, single pairs and batched segments.  Prints one line per case; exits 1 on a mismatch."""
 import os, sys, time
 import numpy as np
@@ -33,7 +33,7 @@ bad = 0
 for c in range(n_cases):
     kind = ["sift", "uniform", "far", "dups"][c % 4]
     big = c % 3 != 2
-    nq = int(rng.integers(16384, 30000)) if big else int(rng.integers(1, 16384))
+    nq = int(rng.integers(12288, 30000)) if big else int(rng.integers(1, 12288))
     nt = int(rng.choice([rng.integers(2, 300), rng.integers(300, 2048), rng.integers(2048, 9000), rng.integers(9000, 26000)]))
     if kind == "far":
         nt = min(nt, 6000)                                                          # every query is re-ranked over all train rows
