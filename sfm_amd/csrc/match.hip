@@ -917,7 +917,11 @@ static int match_launch(sfm_ctx* h, int metric, const void* q, int64_t nq_rows, 
   if (metric == SFM_METRIC_L2_U8) {
     const bool qb4 = qpw == 512;
     const char* d_env = getenv("SFM_MATCH_DIRECT");        // test / tuning knob: "0" = the LDS kernel also for the large case
-    const bool direct = qb4 && !(d_env && d_env[0] == '0');
+    // one pair at dim 128: the LDS-free kernel, with 4 query blocks per wave from 12,288 queries on and 2 below (8-20 % faster
+    // than the LDS kernel at 2,000 .. 11,000 queries against 4,000 .. 50,000 train rows); the LDS kernel serves the batched
+    // form, the smaller dims and the smallest pairs
+    const bool direct2 = !wg && dim == 128 && !qb4 && (double)nq_rows * (double)nt_rows >= 8e6;      // below: launch-bound, the LDS kernel's lighter pre-pass wins by ~3 us
+    const bool direct = (qb4 || direct2) && !(d_env && d_env[0] == '0');
     if (direct)
       hipLaunchKernelGGL(k_train_tile_u8, dim3((unsigned)((nt_rows + 31) >> 5)), dim3(256), 0, h->stream, t8, nt_rows, w.tf, w.th, w.par, w.fix_cnt);
     else
@@ -931,7 +935,8 @@ static int match_launch(sfm_ctx* h, int metric, const void* q, int64_t nq_rows, 
     sfm_prof_begin(h, SFM_PROF_KNN);
 #define KNN_LAUNCH(KS, QB, F) hipLaunchKernelGGL((k_knn2_u8<KS, QB, F>), dim3(grid), dim3(256), 0, h->stream, q8, nq_rows, w.tf, nt_rows, w.th, w.par, w.qn, nsplit, rps, wg, n_out, w.part, w.u2)
     if (direct) {
-      hipLaunchKernelGGL((k_knn2_u8_direct<4>), dim3(grid), dim3(256), 0, h->stream, q8, nq_rows, w.tf, nt_rows, w.th, w.par, w.qn, nsplit, rps, w.part, w.u2);
+      if (direct2) hipLaunchKernelGGL((k_knn2_u8_direct<2>), dim3(grid), dim3(256), 0, h->stream, q8, nq_rows, w.tf, nt_rows, w.th, w.par, w.qn, nsplit, rps, w.part, w.u2);
+      else hipLaunchKernelGGL((k_knn2_u8_direct<4>), dim3(grid), dim3(256), 0, h->stream, q8, nq_rows, w.tf, nt_rows, w.th, w.par, w.qn, nsplit, rps, w.part, w.u2);
     } else if (filter) {
       if (qb4) KNN_LAUNCH(4, 4, true); else if (dim == 128) KNN_LAUNCH(4, 2, true); else if (dim == 64) KNN_LAUNCH(2, 2, true); else KNN_LAUNCH(1, 2, true);
     } else {
