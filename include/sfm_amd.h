@@ -60,7 +60,8 @@ int sfm_profile_read(sfm_handle h, int slot, double* total_ms_host, int64_t* cou
 enum {
   SFM_METRIC_L2_U8   = 0,  /* uint8 [n,dim], dim % 32 == 0 (SIFT: 128): exact integer d^2 on i8 MFMA */
   SFM_METRIC_L2_F32  = 1,  /* float32 [n,dim]: sequential float32 sum of (a-b)^2 (general floats)   */
-  SFM_METRIC_HAMMING = 2   /* uint8 [n,dim] bit strings (ORB: dim=32), popcount                      */
+  SFM_METRIC_HAMMING = 2   /* uint8 [n,dim] bit strings, dim 16 / 32 (ORB) / 64 bytes: popcount distance;
+                              128 / 256 bits run as exact uint8 L2 over unpacked bits on the i8 MFMA path       */
 };
 
 int sfm_match_workspace_bytes(int metric, int64_t nq, int64_t nt, int dim, int64_t* bytes_host);

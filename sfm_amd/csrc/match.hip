@@ -252,7 +252,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(KNN_WAVES, 
     constexpr int TILES = CHUNK / 32, STEPS = TILES * QB;
     // with four query blocks a tile is 16 MFMAs long: one operand set, refilled behind the tile's last chain (the other
     // wave of the SIMD covers the LDS round trip), leaves the registers to the query fragments
-    constexpr int SETS = (QB >= 4 || KNN_WAVES >= 3) ? 1 : 2;
+    constexpr int SETS = (QB * KS >= 16 || KNN_WAVES >= 3) ? 1 : 2;
     v4i at[SETS][KS];
     v16i th[SETS];       // accumulator start values of the 16 train rows a lane's registers hold: rows (r&3) + 8 (r>>2) + 4 half
     int4 kp[4];          // parity bits of the rows of the tile being ranked (one set: fetched right after the previous tile's last ranking)
@@ -739,6 +739,20 @@ __global__ __launch_bounds__(256) void k_merge_splits(int64_t nq, int nsplit, co
   idx1[qi] = b1i; idx2[qi] = b2i; d1[qi] = b1d; d2[qi] = b2d;
 }
 
+// Hamming on the int8 matrix path: over bits unpacked to bytes b in {127, 128} the uint8 L2 d^2 = sum (b_q - b_t)^2 IS the
+// number of differing bits, with the same tie rule (lowest train index) - so ORB descriptors of 128 / 256 bits run through
+// k_knn2_u8 / k_knn2_u8_direct as "dim 128 / 256 uint8 rows", and the merge reports d^2 itself (take_root = 0) where L2 takes
+// the root.  One thread per input byte -> 8 output bytes.
+__global__ __launch_bounds__(256) void k_unpack_bits(const uint8_t* __restrict__ x, int64_t n_bytes, uint8_t* __restrict__ out) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n_bytes) return;
+  const uint32_t v = x[i];
+  uint2 o;
+  o.x = 0x7F7F7F7Fu + ((v & 1u) | ((v & 2u) << 7) | ((v & 4u) << 14) | ((v & 8u) << 21));
+  o.y = 0x7F7F7F7Fu + (((v >> 4) & 1u) | ((v & 32u) << 3) | ((v & 64u) << 10) | ((v & 128u) << 17));
+  *(uint2*)(out + i * 8) = o;
+}
+
 // L2 / uint8: the per-split candidates carry the exact integer d^2 (as float32).  Merge by (d^2, index), take the
 // correctly rounded float32 root, and list the queries whose second neighbour lies where sqrtf stops being
 // injective (d^2 >= 2^22): those are re-ranked on the float32 value by k_knn2_u8_rerank.
@@ -746,7 +760,7 @@ __global__ __launch_bounds__(256) void k_merge_splits(int64_t nq, int nsplit, co
 __global__ __launch_bounds__(256) void k_merge_splits_u8(int64_t nq, int nsplit, const Cand* __restrict__ part,
                                                          int* __restrict__ idx1, int* __restrict__ idx2,
                                                          float* __restrict__ d1, float* __restrict__ d2,
-                                                         int* __restrict__ fix_cnt, int* __restrict__ fix_list) {
+                                                         int* __restrict__ fix_cnt, int* __restrict__ fix_list, int take_root) {
   const int64_t qi = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (qi >= nq) return;
   float b1d = 3.0e38f, b2d = 3.0e38f; int b1i = -1, b2i = -1;
@@ -755,8 +769,9 @@ __global__ __launch_bounds__(256) void k_merge_splits_u8(int64_t nq, int nsplit,
     top2_insert(c[0].d, c[0].i, b1d, b1i, b2d, b2i);
     top2_insert(c[1].d, c[1].i, b1d, b1i, b2d, b2i);
   }
-  idx1[qi] = b1i; idx2[qi] = b2i; d1[qi] = sqrt_rn_f32(b1d); d2[qi] = sqrt_rn_f32(b2d);
-  if (b2d >= D2_SQRT_INJECTIVE_BELOW) fix_list[atomicAdd(fix_cnt, 1)] = (int)qi;     // list order is irrelevant: one writer per query
+  idx1[qi] = b1i; idx2[qi] = b2i;
+  d1[qi] = take_root ? sqrt_rn_f32(b1d) : b1d; d2[qi] = take_root ? sqrt_rn_f32(b2d) : b2d;
+  if (take_root && b2d >= D2_SQRT_INJECTIVE_BELOW) fix_list[atomicAdd(fix_cnt, 1)] = (int)qi;     // list order is irrelevant: one writer per query
 }
 
 // One workgroup per listed query (grid-stride over the list, whose length is only known on the device): every
@@ -879,13 +894,18 @@ __global__ __launch_bounds__(256) void k_f32_to_u8(const float* __restrict__ src
 // workspace carve (bytes): per-split candidates | train norms | query norms | ratio scratch | re-rank list + counter |
 // (batched only) workgroup records + segment table
 struct MatchWs {
-  Cand* part; uint8_t* tf; int* th; int* par; int* qn; int* u2; int* fix_list; int* fix_cnt; char* plan; int64_t total;
+  Cand* part; uint8_t* tf; uint8_t* qbits; uint8_t* tbits; int* th; int* par; int* qn; int* u2; int* fix_list; int* fix_cnt; char* plan; int64_t total;
 };
-static MatchWs match_ws_carve(char* ws, int64_t n_out, int64_t nt_rows, int64_t nq_rows, int64_t plan_bytes) {
+static MatchWs match_ws_carve(char* ws, int64_t n_out, int64_t nt_rows, int64_t nq_rows, int64_t plan_bytes, bool bits = false) {
   MatchWs w;
   int64_t off = 0;
   w.part = (Cand*)(ws + off); off += align_up(8 * n_out * 2 * (int64_t)sizeof(Cand), 256);   // nsplit <= 8
-  w.tf = (uint8_t*)(ws + off); off += align_up((nt_rows + 32) * 128, 256);                      // int8 copy of the train rows + padding (dim <= 128)
+  w.tf = (uint8_t*)(ws + off); off += align_up((nt_rows + 32) * (bits ? 256 : 128), 256);       // int8 copy of the train rows + padding (dim <= 128; 256 for unpacked bits)
+  w.qbits = w.tbits = nullptr;
+  if (bits) {                                                                                  // Hamming: rows unpacked to one byte per bit (<= 256 bits)
+    w.qbits = (uint8_t*)(ws + off); off += align_up(nq_rows * 256, 256);
+    w.tbits = (uint8_t*)(ws + off); off += align_up(nt_rows * 256, 256);
+  }
   w.th = (int*)(ws + off); off += align_up((nt_rows + 32) * 4, 256);
   w.par = (int*)(ws + off); off += align_up((nt_rows + 1) * 4, 256);
   w.qn = (int*)(ws + off); off += align_up(nq_rows * 4, 256);
@@ -901,7 +921,7 @@ static MatchWs match_ws_carve(char* ws, int64_t n_out, int64_t nt_rows, int64_t 
 extern "C" int sfm_match_workspace_bytes(int metric, int64_t nq, int64_t nt, int dim, int64_t* bytes) {
   if (!bytes || nq < 0 || nt < 0 || dim <= 0) return SFM_ERR_ARG;
   (void)metric;
-  *bytes = match_ws_carve(nullptr, nq, nt, nq, 0).total;
+  *bytes = match_ws_carve(nullptr, nq, nt, nq, 0, metric == SFM_METRIC_HAMMING && dim <= 32).total;
   return SFM_OK;
 }
 
@@ -909,7 +929,7 @@ extern "C" int sfm_match_workspace_bytes(int metric, int64_t nq, int64_t nt, int
 static int match_launch(sfm_ctx* h, int metric, const void* q, int64_t nq_rows, const void* t, int64_t nt_rows, int dim,
                         int nsplit, int64_t rps, int64_t qpw /* queries per workgroup */, int64_t filter_rows /* train rows of the longest segment */,
                         const MatchWG* wg, unsigned grid, int64_t n_out, MatchSegs segs,
-                        const MatchWs& w, int32_t* idx1, int32_t* idx2, float* d1, float* d2) {
+                        const MatchWs& w, int32_t* idx1, int32_t* idx2, float* d1, float* d2, bool take_root = true) {
   const uint8_t* q8 = (const uint8_t*)q; const uint8_t* t8 = (const uint8_t*)t;
   const uint32_t* qq = (const uint32_t*)q; const uint32_t* tt = (const uint32_t*)t;
   if (wg)   // segments choose their own number of splits: slots a segment does not use must read as "empty" (i = -1)
@@ -938,14 +958,14 @@ static int match_launch(sfm_ctx* h, int metric, const void* q, int64_t nq_rows, 
       if (direct2) hipLaunchKernelGGL((k_knn2_u8_direct<2>), dim3(grid), dim3(256), 0, h->stream, q8, nq_rows, w.tf, nt_rows, w.th, w.par, w.qn, nsplit, rps, w.part, w.u2);
       else hipLaunchKernelGGL((k_knn2_u8_direct<4>), dim3(grid), dim3(256), 0, h->stream, q8, nq_rows, w.tf, nt_rows, w.th, w.par, w.qn, nsplit, rps, w.part, w.u2);
     } else if (filter) {
-      if (qb4) KNN_LAUNCH(4, 4, true); else if (dim == 128) KNN_LAUNCH(4, 2, true); else if (dim == 64) KNN_LAUNCH(2, 2, true); else KNN_LAUNCH(1, 2, true);
+      if (qb4) KNN_LAUNCH(4, 4, true); else if (dim == 256) KNN_LAUNCH(8, 2, true); else if (dim == 128) KNN_LAUNCH(4, 2, true); else if (dim == 64) KNN_LAUNCH(2, 2, true); else KNN_LAUNCH(1, 2, true);
     } else {
-      if (qb4) KNN_LAUNCH(4, 4, false); else if (dim == 128) KNN_LAUNCH(4, 2, false); else if (dim == 64) KNN_LAUNCH(2, 2, false); else KNN_LAUNCH(1, 2, false);
+      if (qb4) KNN_LAUNCH(4, 4, false); else if (dim == 256) KNN_LAUNCH(8, 2, false); else if (dim == 128) KNN_LAUNCH(4, 2, false); else if (dim == 64) KNN_LAUNCH(2, 2, false); else KNN_LAUNCH(1, 2, false);
     }
 #undef KNN_LAUNCH
     sfm_prof_end(h, SFM_PROF_KNN);
     hipLaunchKernelGGL(k_merge_splits_u8, dim3(cdiv(n_out, 256)), dim3(256), 0, h->stream, n_out, wg ? 8 : nsplit, w.part, idx1, idx2,
-                       d1, d2, w.fix_cnt, w.fix_list);
+                       d1, d2, w.fix_cnt, w.fix_list, take_root ? 1 : 0);
     hipLaunchKernelGGL(k_knn2_u8_rerank, dim3(n_out < 2048 ? (unsigned)n_out : 2048u), dim3(256), 0, h->stream, q8, t8, nt_rows, dim,
                        segs, w.fix_cnt, w.fix_list, idx1, idx2, d1, d2);
   } else {
@@ -989,14 +1009,20 @@ extern "C" int sfm_match_knn2(sfm_handle h, int metric, const void* q, int64_t n
   if (nq < 1 || nt < 2) return sfm_fail(h, SFM_ERR_ARG, "sfm_match_knn2", "needs nq >= 1 and nt >= 2");
   if (nt > 0x7FFFFF00LL || nq > 0x7FFFFF00LL) return sfm_fail(h, SFM_ERR_ARG, "sfm_match_knn2", "too many rows");
   int rc = match_check_metric(h, metric, dim, "sfm_match_knn2"); if (rc) return rc;
-  const MatchWs w = match_ws_carve((char*)workspace, nq, nt, nq, 0);
+  const bool bits = metric == SFM_METRIC_HAMMING && dim <= 32;      // 128 / 256 bits: on the int8 kernels (k_unpack_bits)
+  const MatchWs w = match_ws_carve((char*)workspace, nq, nt, nq, 0, bits);
   if (workspace_bytes < w.total) return sfm_fail(h, SFM_ERR_WORKSPACE, "sfm_match_knn2", "workspace too small");
+  if (bits) {
+    hipLaunchKernelGGL(k_unpack_bits, dim3(cdiv(nq * dim, 256)), dim3(256), 0, h->stream, (const uint8_t*)q, nq * dim, w.qbits);
+    hipLaunchKernelGGL(k_unpack_bits, dim3(cdiv(nt * dim, 256)), dim3(256), 0, h->stream, (const uint8_t*)t, nt * dim, w.tbits);
+    q = w.qbits; t = w.tbits; metric = SFM_METRIC_L2_U8; dim *= 8;
+  }
   int nsplit; int64_t rps;
   const int64_t qpw = match_qpw(metric, dim, nq, false);
   match_tiling(metric, nq, qpw, nt, &nsplit, &rps);
   const unsigned grid = cdiv(nq, qpw) * nsplit;
   MatchSegs none = {nullptr, nullptr, nullptr, nullptr, 0};
-  return match_launch(h, metric, q, nq, t, nt, dim, nsplit, rps, qpw, nt, nullptr, grid, nq, none, w, idx1, idx2, d1, d2);
+  return match_launch(h, metric, q, nq, t, nt, dim, nsplit, rps, qpw, nt, nullptr, grid, nq, none, w, idx1, idx2, d1, d2, !bits);
 }
 
 // ---- batched: every image pair of a preprocessing step in one launch
@@ -1010,7 +1036,7 @@ extern "C" int sfm_match_batched_workspace_bytes(int metric, int32_t n_seg, cons
                 q_end_host, t_beg_host, t_end_host, &wgs, &out_ptr);
   *n_out_host = out_ptr[n_seg];
   const int64_t plan_bytes = (int64_t)wgs.size() * sizeof(MatchWG) + 4 * ((int64_t)n_seg + 1) * 8 + 256;
-  *bytes_host = match_ws_carve(nullptr, out_ptr[n_seg] > 0 ? out_ptr[n_seg] : 1, nt_rows, nq_rows, plan_bytes).total;
+  *bytes_host = match_ws_carve(nullptr, out_ptr[n_seg] > 0 ? out_ptr[n_seg] : 1, nt_rows, nq_rows, plan_bytes, metric == SFM_METRIC_HAMMING).total;
   return SFM_OK;
 }
 
@@ -1029,13 +1055,21 @@ extern "C" int sfm_match_knn2_batched(sfm_handle h, int metric, const void* q, i
     if (q_end_host[s] > q_beg_host[s] && t_end_host[s] - t_beg_host[s] < 2)
       return sfm_fail(h, SFM_ERR_ARG, "sfm_match_knn2_batched", "a segment with queries needs at least 2 train rows");
   }
+  const bool bits = metric == SFM_METRIC_HAMMING && dim <= 32;      // 128 / 256 bits: on the int8 kernels (k_unpack_bits)
+  const int plan_metric = bits ? SFM_METRIC_L2_U8 : metric, plan_dim = bits ? dim * 8 : dim;
   std::vector<MatchWG> wgs; std::vector<int64_t> out_ptr;
-  plan_segments(metric, dim, n_seg, q_beg_host, q_end_host, t_beg_host, t_end_host, &wgs, &out_ptr);
+  plan_segments(plan_metric, plan_dim, n_seg, q_beg_host, q_end_host, t_beg_host, t_end_host, &wgs, &out_ptr);
   const int64_t n_out = out_ptr[n_seg];
   if (n_out < 1) return sfm_fail(h, SFM_ERR_ARG, "sfm_match_knn2_batched", "no query rows");
   const int64_t wg_bytes = (int64_t)wgs.size() * sizeof(MatchWG), seg_bytes = ((int64_t)n_seg + 1) * 8;
-  const MatchWs w = match_ws_carve((char*)workspace, n_out, nt_rows, nq_rows, wg_bytes + 4 * seg_bytes + 256);
+  const MatchWs w = match_ws_carve((char*)workspace, n_out, nt_rows, nq_rows, wg_bytes + 4 * seg_bytes + 256, metric == SFM_METRIC_HAMMING);
   if (workspace_bytes < w.total) return sfm_fail(h, SFM_ERR_WORKSPACE, "sfm_match_knn2_batched", "workspace too small");
+  if (bits) {
+    const bool same = q == t && nq_rows == nt_rows;                  // match_pairs hands one array for both sides
+    hipLaunchKernelGGL(k_unpack_bits, dim3(cdiv(nt_rows * dim, 256)), dim3(256), 0, h->stream, (const uint8_t*)t, nt_rows * dim, w.tbits);
+    if (!same) hipLaunchKernelGGL(k_unpack_bits, dim3(cdiv(nq_rows * dim, 256)), dim3(256), 0, h->stream, (const uint8_t*)q, nq_rows * dim, w.qbits);
+    q = same ? w.tbits : w.qbits; t = w.tbits; metric = SFM_METRIC_L2_U8; dim *= 8;
+  }
   // plan -> device: workgroup records, then q_beg | t_beg | t_end | out_ptr
   char* dp = w.plan;
   int64_t* d_seg = (int64_t*)(dp + align_up(wg_bytes, 256));
@@ -1051,7 +1085,7 @@ extern "C" int sfm_match_knn2_batched(sfm_handle h, int metric, const void* q, i
   int64_t longest = 0;
   for (int s = 0; s < n_seg; ++s) longest = (t_end_host[s] - t_beg_host[s]) > longest ? (t_end_host[s] - t_beg_host[s]) : longest;
   return match_launch(h, metric, q, nq_rows, t, nt_rows, dim, 1, 0, 256, longest, (const MatchWG*)dp, (unsigned)wgs.size(), n_out, segs, w,
-                      idx1, idx2, d1, d2);
+                      idx1, idx2, d1, d2, !bits);
 }
 
 extern "C" int sfm_match_ratio(sfm_handle h, int64_t nq, const int32_t* idx1, const float* d1, const float* d2,

@@ -73,6 +73,23 @@ def test_hamming_matches_oracle(gpu_ready, nq, nt):
     assert_knn_equal(gpu_knn2(b1, b2, "auto"), mo.knn2(b1, b2, "hamming"))
 
 
+@pytest.mark.parametrize("nq,nt,nbytes", [(700, 3000, 16), (4001, 6100, 32), (13000, 2500, 16), (257, 5000, 64), (2, 2, 32)])
+def test_hamming_sizes_and_widths(gpu_ready, nq, nt, nbytes):
+    """Hamming on 128 / 256 bits runs as exact uint8 L2 over the unpacked bits on the int8 kernels (k_unpack_bits; 128 bits can
+    take the LDS-free kernel, 256 bits the dim-256 instantiation, both with the candidate filter from 2,048 train rows on);
+    512 bits stay on the popcount kernel.  All against the NumPy oracle: many exact ties (distances are small integers), so
+    the lowest-train-index rule decides most second neighbours."""
+    from oracle import matcher_oracle as mo
+    rng = np.random.default_rng(nq + nbytes)
+    b1 = rng.integers(0, 256, size=(nq, nbytes), dtype=np.uint8)
+    b2 = rng.integers(0, 256, size=(nt, nbytes), dtype=np.uint8)
+    k = min(nq, nt) // 2
+    b2[:k] = b1[:k] ^ (rng.integers(0, 256, size=(k, nbytes), dtype=np.uint8) & rng.integers(0, 256, size=(k, nbytes), dtype=np.uint8)
+                       & rng.integers(0, 256, size=(k, nbytes), dtype=np.uint8))
+    b2[k: k + k // 4] = b2[:k // 4]                                  # exact duplicates among the train rows
+    assert_knn_equal(gpu_knn2(b1, b2, "hamming"), mo.knn2(b1, b2, "hamming"))
+
+
 def test_match_features_contract(gpu_ready):
     """List of DMatch-like objects, query-ordered, one per query, strict ratio test in double."""
     from oracle import matcher_oracle as mo

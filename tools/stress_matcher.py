@@ -44,6 +44,18 @@ for c in range(n_cases):
     ok = same(got, ba_c.knn2_u8(q, t))
     bad += not ok
     print(f"case {c:2d} {kind:8s} nq={nq:6d} nt={nt:6d} {'ok' if ok else 'MISMATCH'}  {time.perf_counter() - t0:.2f}s", flush=True)
+# Hamming (ORB) on 128 / 256 / 512 bits against the NumPy oracle: the first two run as uint8 L2 over unpacked bits
+from oracle import matcher_oracle as mo
+for c in range(6):
+    nbytes = [16, 32, 64][c % 3]
+    nq = int(rng.integers(1, 14000)); nt = int(rng.integers(2, 9000))
+    b1 = rng.integers(0, 256, size=(nq, nbytes), dtype=np.uint8); b2 = rng.integers(0, 256, size=(nt, nbytes), dtype=np.uint8)
+    k = min(nq, nt) // 2
+    b2[:k] = b1[:k] ^ (rng.integers(0, 256, size=(k, nbytes), dtype=np.uint8) & rng.integers(0, 256, size=(k, nbytes), dtype=np.uint8))
+    i1, i2, a, b = matcher.knn2(torch.from_numpy(b1).cuda(), torch.from_numpy(b2).cuda(), "hamming")
+    ok = same((i1.cpu().numpy(), i2.cpu().numpy(), a.cpu().numpy(), b.cpu().numpy()), mo.knn2(b1, b2, "hamming"))
+    bad += not ok
+    print(f"hamming {c} bytes={nbytes} nq={nq} nt={nt} {'ok' if ok else 'MISMATCH'}", flush=True)
 # batched segments, some with more than 2,048 train rows (filter on inside a batch)
 for c in range(4):
     sizes = [int(rng.integers(50, 5000)) for _ in range(6)]
