@@ -330,6 +330,24 @@ def main():
                    "workload": f"{n} x {n} x 128 uint8 SIFT-like, brute-force L2 kNN(2) + ratio 0.75 + compaction",
                    "ms_per_pair_of_images": tm / args.match_reps * 1e3, "n_matches": int(mq.shape[0]),
                    "dtype": "u8/i32", "roofline": mroof}
+        # the in-tree alternative feature type: ORB, 256-bit strings, Hamming distance (find_matches.py:144) - exact uint8 L2
+        # over the unpacked bits on the same int8 kernels
+        try:
+            n_orb = min(n, 30000)
+            rng_o = np.random.default_rng(1006)
+            oq = torch.from_numpy(rng_o.integers(0, 256, size=(n_orb, 32), dtype=np.uint8)).cuda()
+            ot = torch.from_numpy(rng_o.integers(0, 256, size=(n_orb, 32), dtype=np.uint8)).cuda()
+            for _ in range(2):
+                mt.knn2(oq, ot, "hamming", device=local_rank)
+            torch.cuda.synchronize()
+            t_o = time.perf_counter()
+            for _ in range(5):
+                mt.knn2(oq, ot, "hamming", device=local_rank)
+            torch.cuda.synchronize()
+            matcher["orb_hamming_256"] = {"value": float(n_orb) * n_orb * 5 / (time.perf_counter() - t_o), "unit": "pairs/s",
+                                          "workload": f"{n_orb} x {n_orb} x 256-bit ORB-like, kNN(2), rank 0 only"}
+        except Exception as e:      # a secondary row must not take the line down
+            matcher["orb_hamming_256"] = {"error": repr(e)}
 
     # ---- the reference's real call pattern: one match_features per image pair of a preprocessing step
     # (find_matches.py:329-350), a few hundred to a few thousand descriptors per image: all pairs in ONE launch
