@@ -436,7 +436,7 @@ __global__ __launch_bounds__(256) void k_train_tile_u8(const uint8_t* __restrict
 }
 
 template <int QB>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_knn2_u8_direct(
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(QB == 2 ? 3 : 2, QB == 2 ? 3 : 2))) void k_knn2_u8_direct(
     const uint8_t* __restrict__ q, int64_t nq, const uint8_t* __restrict__ xt, int64_t nt, const int* __restrict__ th_t,
     const int* __restrict__ pb_t, const int* __restrict__ qn, int nsplit, int64_t rows_per_split, Cand* __restrict__ part, int* u2g) {
   constexpr int KS = 4, DIM = 128;
