@@ -138,6 +138,20 @@ def match_arrays(desc1, desc2, ratio=0.75, metric="auto", device=0):
     return q.cpu().numpy(), t.cpu().numpy(), d.cpu().numpy()
 
 
+_STAGE = {}
+
+
+def _pinned_stage(n_bytes):
+    """A page-locked uint8 buffer of at least n_bytes, kept across calls (grow-only, doubled on growth)."""
+    import torch
+    buf = _STAGE.get("buf")
+    if buf is None or buf.numel() < n_bytes:
+        size = max(n_bytes, 2 * (buf.numel() if buf is not None else 0), 1 << 20)
+        buf = torch.empty(size, dtype=torch.uint8, pin_memory=True)
+        _STAGE["buf"] = buf
+    return buf
+
+
 def _prepare_sets(descs, metric, dev, h):
     """Descriptor sets of several images -> one device array (rows back to back), its row offsets and the metric code.
     Same dtype rules as knn2: float32 sets whose values are all integers in [0,255] go to the exact uint8 path."""
@@ -150,7 +164,15 @@ def _prepare_sets(descs, metric, dev, h):
         raise ValueError("descriptor sets must be [n, dim] arrays of one dtype and dim")
     ptr = np.zeros(len(arrs) + 1, dtype=np.int64)
     np.cumsum([a.shape[0] for a in arrs], out=ptr[1:])
-    allrows = torch.from_numpy(np.concatenate(arrs, axis=0)).to(dev)
+    # rows back to back straight into a page-locked staging buffer (kept and grown across calls), one asynchronous copy from
+    # there: the concatenation into pageable memory plus its staged upload were 0.3 ms of a 0.8 ms call at 18 x 2,000 x 128
+    n_bytes = int(ptr[-1]) * dim * arrs[0].dtype.itemsize
+    stage = _pinned_stage(max(n_bytes, 1))
+    host = stage[:n_bytes].numpy().view(arrs[0].dtype).reshape(int(ptr[-1]), dim)
+    if int(ptr[-1]) > 0:
+        np.concatenate(arrs, axis=0, out=host)
+    allrows = torch.from_numpy(host).to(dev, non_blocking=True)
+    torch.cuda.current_stream(dev).synchronize()          # the staging buffer is reused by the next call
     metric = _resolve_metric(allrows, allrows, metric)
     if metric == "hamming":
         if allrows.dtype != torch.uint8:
