@@ -162,7 +162,7 @@ def main():
     def pmc_traffic(kernel_key):
         """HBM bytes per launch from the committed PMC summary of the same workload (rocprofv3 cannot run inside
         this process); collected and corrected as MI355X_MICROARCH.md prescribes."""
-        for name in ("r02_pmc_summary.json", "r01_pmc_summary.json"):
+        for name in ("r03_pmc_summary.json", "r02_pmc_summary.json", "r01_pmc_summary.json"):
             try:
                 pmc = json.load(open(os.path.join(ROOT, "profiles", name)))
                 wl = pmc["workload"]
@@ -207,24 +207,32 @@ def main():
                               "mfma", n_sys ** 3 / 3.0, 1e12, FP64_MFMA_PEAK_TFLOPS, "TFLOP/s", "chol",
                               note=("latency chain of %d dependent 64-column steps" % ((n_sys + 63) // 64)) if n_sys < 4096
                               else "256-column strips + rank-256 trailing updates"))
+    # k_schur_items is a gather: its roofline is priced on the UNIQUE bytes it has to touch per launch (every G block once +
+    # the pair ids), which is what an ideal cache hierarchy would move from HBM.  The rate at which blocks are pulled through
+    # L2 (every block ~10 times) is reported beside it as l2_gather_rate, never as `frac`.
+    n_loc, n_pairs = main["n_obs_local"], main["n_pairs"]
+    schur_unique = n_loc * 3 * d * 8 + n_pairs * 8.0
+    schur_gathered = (2.0 * n_pairs - n_loc) * 3 * d * 8 + n_loc * 24.0
     roofs = cam_roofs + [
-        roof("k_schur_items (S blocks = -sum G_k G_k2^T per camera pair, f64 MFMA)", "hbm",
-             (2.0 * main["n_pairs"] - main["n_obs_local"]) * 3 * d * 8 + main["n_obs_local"] * 24.0, 1e9, HBM_PEAK_GBS, "GB/s",
+        roof("k_schur_items (S blocks = -sum G_k G_k2^T per camera pair, f64 MFMA)", "hbm", schur_unique, 1e9, HBM_PEAK_GBS, "GB/s",
              "schur_items", "k_schur_items",
-             note="a gather: `achieved` counts the G blocks pulled per launch (2 x 240 B per camera pair - one block and the 24 B "
-                  "of e_j for the self-pairs of the diagonal blocks, whose accumulator column 10 is the right-hand side -, every block ~10 times), "
-                  "`traffic` what leaves the L2s for the Infinity Cache / HBM; the unique data is %.0f MB of G + %.0f MB of pair "
-                  "indices - see unique_bytes / refetch" % (main["n_obs_local"] * 3 * d * 8 / 1e6, main["n_pairs"] * 8 / 1e6)),
+             note="a gather: `achieved` / `frac` price the unique data of a launch (%.0f MB of G + %.0f MB of pair indices) "
+                  "against the HBM peak; `traffic` is what leaves the L2s for the Infinity Cache / HBM (PMC), `wasted_traffic` = "
+                  "traffic / unique bytes, `l2_gather_rate` the rate at which G blocks are pulled through L2 (2 x %d B per camera "
+                  "pair), `flop_frac` the useful 2 x 3 x d x d FLOP per pair against the fp64 MFMA rate" % (
+                      n_loc * 3 * d * 8 / 1e6, n_pairs * 8 / 1e6, 3 * d * 8)),
         roof("k_lin_obs (residual + 2x(%d+3) Jacobian + Huber scaling)" % d, "hbm", float(bytes_per_obs) * main["n_obs_local"],
              1e9, HBM_PEAK_GBS, "GB/s", "lin_obs", "k_lin_obs"),
     ]
     roofs = [r for r in roofs if r]
     for r in roofs:
         if r["kernel"].startswith("k_schur_items"):
-            r["unique_bytes"] = main["n_obs_local"] * 3 * d * 8 + main["n_pairs"] * 8
-            r["frac_unique_bytes"] = round(r["unique_bytes"] / (r["avg_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)
+            sec = r["avg_us"] * 1e-6
+            r["unique_bytes"] = schur_unique
+            r["l2_gather_rate"] = {"value": round(schur_gathered / sec / 1e9, 1), "unit": "GB/s", "bytes_per_launch": schur_gathered}
+            r["flop_frac"] = round(2.0 * 3 * d * d * n_pairs / sec / 1e12 / FP64_MFMA_PEAK_TFLOPS, 4)
             if r["traffic"]:
-                r["refetch"] = round(r["traffic"] / r["unique_bytes"], 2)
+                r["wasted_traffic"] = round(r["traffic"] / r["unique_bytes"], 2)
             # the whole Schur stage (items + assemble + right-hand side) shares this entry's time share
             r["time_share"] = kernels["schur"]["share"]
             r["stage_us"] = kernels["schur"]["us_per_launch"]

@@ -201,7 +201,8 @@ typedef struct {
 
 enum { SFM_SC_COST = 0, SFM_SC_GNORM2 = 1, SFM_SC_GINF = 2, SFM_SC_PNORM2 = 3, SFM_SC_PQ = 4,
        SFM_SC_JS2 = 5, SFM_SC_GTS = 6, SFM_SC_COST_NEW = 7, SFM_SC_SNORM2 = 8, SFM_SC_XNEW_NORM2 = 9,
-       SFM_SC_CHOL_FAIL = 10, SFM_SC_HDIAG = 11 /* max diag(H) */, SFM_SC_COUNT = 16 };
+       SFM_SC_CHOL_FAIL = 10 /* 0 ok, 1 not positive definite, 2 triangular solve stalled, 3 step not finite */,
+       SFM_SC_HDIAG = 11 /* max diag(H) */, SFM_SC_COUNT = 16 };
 
 /* Layout of the workspace of a problem.  The workspace (total_bytes, device memory) is the caller's: bind it
  * before the first stage; workspace == NULL makes the library allocate (and own) one.  rec / recB hold
@@ -240,7 +241,10 @@ int sfm_ba_finish_solve(sfm_handle h, sfm_ba_problem p, int want_q);            
  * S v = (B + alpha I) v - W (C + alpha I)^-1 W^T v (two passes over G per product), preconditioned with the exact
  * d x d diagonal blocks of S.  One call = schur_build + schur_solve + finish_solve: afterwards pc / pp hold the step
  * and the scalars PNORM2 (and PQ when want_q) are set; SFM_SC_CHOL_FAIL != 0 when S or a block is not positive
- * definite.  Stops when ||r|| <= rtol ||r_0|| (checked every 8 iterations) or after max_iter iterations per system
+ * definite.  A system that has not reached rtol after max_iter iterations (measured: near convergence of the outer loop,
+ * alpha ~ 1e-3, S nearly singular along the gauge directions, block-Jacobi PCG stalls at 1e-2 .. 1e-4) is never accepted:
+ * the damped solve is then redone by the formed-S route (schur_build / schur_solve / finish_solve, reductions through the
+ * same hook) and counted (sfm_ba_pcg_stats) - an inexact p would silently steer the alpha iteration.  Stops when ||r|| <= rtol ||r_0|| (checked every 8 iterations) or after max_iter iterations per system
  * (want_q solves two).  Multi-rank: `reduce` sums, per call, the right-hand side and the diagonal blocks once and
  * ONE vector of n doubles per iteration - against n(n+1)/2 + n doubles and a replicated factorisation on the dense
  * route; meant for many cameras (BASELINE config 5) and for scaling over GPUs.  iters_host: CG iterations spent. */
@@ -256,6 +260,10 @@ int sfm_ba_read_scalars(sfm_handle h, sfm_ba_problem p, double* out_host);
 /* SFM_CAMERA_SOLVER_CG bookkeeping since the problem was created: CG iterations spent, solves that fell back. */
 int sfm_ba_solver_stats(sfm_ba_problem p, int64_t* cg_iters_host, int64_t* cg_fallbacks_host);
 
+/* sfm_ba_solve_pcg bookkeeping since the problem was created: damped solves that were handed to the formed-S route
+ * because a system ran out of iterations above rtol, and the worst relative residual ||r|| / ||r_0|| PCG had reached there. */
+int sfm_ba_pcg_stats(sfm_ba_problem p, int64_t* fallbacks_host, double* worst_relres_host);
+
 /* ---- the trust-region loop (scipy _lsq/trf.py:401-560 trf_no_bounds + common.py:57-168,222-248,705-717),
  * control flow on the host, every data-parallel stage above on the device.  Same state machine as
  * sfm_amd/trf.py (the host-language mirror the multi-rank CPU tests drive). */
@@ -267,7 +275,7 @@ typedef struct {
   int32_t check_tolerances;       /* 0 turns the gtol / ftol / xtol tests off (throughput runs) */
   int32_t solver;                 /* SFM_SOLVER_DENSE: Schur complement + dense Cholesky; SFM_SOLVER_PCG: sfm_ba_solve_pcg */
   double  pcg_rtol;               /* SFM_SOLVER_PCG: relative residual (<= 0: 1e-13) */
-  int32_t pcg_max_iter;           /* SFM_SOLVER_PCG: iterations per system (<= 0: 4 n, capped at 20000) */
+  int32_t pcg_max_iter;           /* SFM_SOLVER_PCG: iterations per system before the formed-S fallback (<= 0: 400) */
   int32_t reserved;
 } sfm_trf_options;
 typedef struct {

@@ -83,6 +83,7 @@ SIGNATURES = {
     "sfm_ba_get_structure": (C.c_int, [vp, C.POINTER(BAStructureView)]),
     "sfm_ba_get_layout": (C.c_int, [vp, C.POINTER(BALayout)]),
     "sfm_ba_solver_stats": (C.c_int, [vp, C.POINTER(i64), C.POINTER(i64)]),
+    "sfm_ba_pcg_stats": (C.c_int, [vp, C.POINTER(i64), C.POINTER(f64)]),
     "sfm_ba_bind_workspace": (C.c_int, [vp, vp, vp, i64]),
     "sfm_reproj_errors": (C.c_int, [vp, i32, i32, i64, vp, vp, vp, vp, f64, f64, f64, f64, C.c_int, vp]),
     "sfm_ba_solve_pcg": (C.c_int, [vp, vp, f64, C.c_int, f64, i32, REDUCE_FN, vp, C.POINTER(i32)]),

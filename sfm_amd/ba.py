@@ -117,6 +117,13 @@ class GpuBA:
         self.h.lib.sfm_ba_solver_stats(self._pp, C.byref(a), C.byref(b))
         return a.value, b.value
 
+    def pcg_stats(self):
+        """solver="pcg": (damped solves redone by the formed-S route because PCG ran out of iterations, worst relative
+        residual PCG had reached in one of them)."""
+        a, b = C.c_int64(0), C.c_double(0.0)
+        self.h.lib.sfm_ba_pcg_stats(self._pp, C.byref(a), C.byref(b))
+        return a.value, b.value
+
     # ---- structure (inspection / tests)
     def structure(self):
         """The index structure built on the device, as a dict of int32 NumPy arrays (names of sfm_ba_structure)."""
@@ -163,7 +170,7 @@ class GpuBA:
         return s[_lib.SC_COST], math.sqrt(s[_lib.SC_GNORM2]), s[_lib.SC_GINF], s[_lib.SC_HDIAG]
 
     def _pcg_max_iter(self):
-        return int(self.pcg_max_iter) if self.pcg_max_iter else min(4 * self.n, 20000)
+        return int(self.pcg_max_iter) if self.pcg_max_iter else 400      # then the formed-S fallback inside sfm_ba_solve_pcg
 
     def solve(self, alpha, want_q):
         L = self.lay

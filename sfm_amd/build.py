@@ -8,7 +8,10 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 SRC = [os.path.join(HERE, "csrc", f) for f in ("ctx.hip", "ba.hip", "problem.hip", "trf.hip", "dense.hip", "match.hip", "driver.hip")]
-HDR = [os.path.join(HERE, "csrc", f) for f in ("common.h", "dense.h", "ba_internal.h")] + [os.path.join(ROOT, "include", "sfm_amd.h")]
+import glob
+# every header under csrc/ (match_plan.h and trf_loop.h were missing from a hand-kept list once: a stale library then
+# ran under the GPU tests while the CPU sanitizer tests compiled the new header)
+HDR = sorted(glob.glob(os.path.join(HERE, "csrc", "*.h"))) + sorted(glob.glob(os.path.join(ROOT, "include", "*.h")))
 LIB = os.path.join(HERE, "lib", "libsfm_amd.so")
 
 

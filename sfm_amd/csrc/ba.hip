@@ -76,6 +76,8 @@ Lay ba_layout(int64_t C, int64_t P, int64_t N, int64_t D, int64_t n_items, int64
   L.cg_r = take(n); L.cg_z = take(n); L.cg_p = take(n); L.cg_Ap = take(n);
   L.cg_M = take(C * D * D); L.cg_Minv = take(C * D * D);
   L.cg_scal = take(16);
+  L.cg_mail = take(4 * n);               // k_cgs_persist: two slots of n doubles as pairs of 8-byte {tag, half} granules
+  L.cg_warm = take(4 * n);               // warm start of the camera CG: p_c and q_c of the previous damped solve, start vector, scratch
   L.total = o;
   return L;
 }
@@ -546,7 +548,7 @@ __global__ __launch_bounds__(256) void k_build_G(int64_t N, const int* __restric
 // row = (l>>4) + 4*reg.  Pair ids are loaded 64 at a time (coalesced) and broadcast with v_readlane so the
 // 16 gathers of 8 pairs are in flight together.  k_schur_assemble then sums the items of each block in
 // order (bitwise reproducible), adds B_c on the diagonal and writes the block and its mirror.
-template <int D, typename T, int GS>
+template <int D, typename T, int GS, bool KPACK>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) void k_schur_items(const int* __restrict__ xcd_ptr, const int* __restrict__ xcd_items,
                                                      const int* __restrict__ item_beg,
                                                      const int* __restrict__ item_end,
@@ -554,7 +556,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) voi
                                                      const T* __restrict__ G, double* __restrict__ part,
                                                      const int* __restrict__ cam_idx,
                                                      const int* __restrict__ item_ptr, const int* __restrict__ cch_ptr, int n_cams,
-                                                     const double* __restrict__ eobs, double* __restrict__ cch_part) {
+                                                     const double* __restrict__ eobs, double* __restrict__ cch_part,
+                                                     int fuse_rhs) {
   // Gathers are latency-bound (about 5 us under load), so what counts is useful bytes in flight per register:
   // a G block is BB bytes = CH 16-byte chunks, one lane fetches one chunk (global_load_dwordx4) and one
   // instruction fetches BPL whole blocks (float64 D = 10: 4 blocks on 60 lanes, D = 6: 7 on 63; float32 D = 10:
@@ -596,8 +599,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) voi
   const char* Gb = (const char*)G;
   v4d acc = {0.0, 0.0, 0.0, 0.0};
   const int k_first = __builtin_amdgcn_readfirstlane(pair_k[beg]), k2_first = __builtin_amdgcn_readfirstlane(pair_k2[beg]);
-  const bool diag = k_first == k2_first;                  // wave-uniform: a block with one self-pair has nothing else
+  // wave-uniform.  A diagonal block holds nothing but self-pairs UNLESS a camera appears twice on a track (fuse_rhs == 0,
+  // sfm_ba_prob::has_dup): then it is processed like any other block and the right-hand side comes from k_cam_reduce_chunks
+  const bool diag = fuse_rhs && k_first == k2_first;
   const bool e_lane = (row == D) && (m < 3);              // B operand column D
+  // K-packed form (see the MFMA loop): slot s = 4 j + m of MFMA j -> pair s / 3 of the slab, point coordinate s % 3
+  constexpr int NM = (3 * BPL + 3) / 4;                   // MFMAs per full slab (3 for 4 pairs, 6 for 7)
+  const bool krow = row < D, ke_lane = row == D;
+  int koff[NM];                                           // LDS element of this lane's slot in MFMA j; < 0: beyond the slab (reads as zero)
+#pragma unroll
+  for (int j = 0; j < NM; ++j) {
+    const int sl = 4 * j + m, pi = (sl * 11) >> 5;        // sl / 3 for sl < 32
+    koff[j] = (pi < BPL && krow) ? pi * GS + (sl - 3 * pi) * D + row : -1;
+  }
   // two instantiations of the item loop (the off-diagonal one is the kernel as it was: nothing of the diagonal path in it)
   auto run = [&](auto diag_c) __attribute__((always_inline)) {
     constexpr bool DIAG = decltype(diag_c)::value;
@@ -635,6 +649,25 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) voi
           }
           __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
           __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+          if (KPACK) {
+            // the contraction index of a slab is (pair, m): 3 nb slots for nb pairs, 4 per MFMA - four pairs = 12 slots = 3 FULL
+            // v_mfma_f64_16x16x4 instead of 4 with K = 3 of 4 used.  Slot s = 4 j + (lane >> 4) of MFMA j reads pair s / 3,
+            // m = s % 3 (offsets precomputed per lane: koff[j]); pairs past the end of the item were stored as zeros
+            const int nb = (cnt - (u0 + t * BPL)) < BPL ? (cnt - (u0 + t * BPL)) : BPL;
+            const int nm = (3 * nb + 3) >> 2;
+#pragma unroll
+            for (int j = 0; j < NM; ++j) {
+              if (j >= nm) break;                             // wave-uniform
+              const bool in = koff[j] >= 0;
+              const double a = in ? (double)((const T*)sA)[koff[j]] : 0.0;
+              double b;
+              if (DIAG) {
+                const int sl = 4 * j + m, pi = (sl * 11) >> 5;
+                b = in ? a : ((ke_lane && pi < nb) ? s_e[w][u0 + t * BPL + pi][sl - 3 * pi] : 0.0);
+              } else b = in ? (double)((const T*)sB)[koff[j]] : 0.0;
+              acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
+            }
+          } else {
 #pragma unroll
           for (int bb = 0; bb < BPL; ++bb) {
             if (u0 + t * BPL + bb >= cnt) break;            // wave-uniform
@@ -643,6 +676,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) voi
             if (DIAG) b = valid ? a : (e_lane ? s_e[w][u0 + t * BPL + bb][m] : 0.0);
             else b = valid ? (double)((const T*)sB)[bb * GS + off] : 0.0;
             acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
+          }
           }
           __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");     // the slab is rewritten by the next t
         }
@@ -1077,6 +1111,7 @@ extern "C" int sfm_ba_linearize(sfm_handle h, sfm_ba_problem p, const double* x)
   const int C = p->n_cams, P = p->n_pts, D = p->cam_dim, n = C * D;
   const int64_t N = p->n_obs;
   const double* pts = x + (size_t)n;
+  p->warm_pc_ok = p->warm_qc_ok = 0;                  // a new linearisation: the previous damped solves are another system's
   DISPATCH_DT(D, p->precision, {
     hipLaunchKernelGGL(k_campre<DD>, dim3(cdiv(C, 64)), dim3(64), 0, h->stream, x, C, p->fx0, p->fy0, p->cx0,
                        p->cy0, WS(L, campre));
@@ -1133,14 +1168,22 @@ extern "C" int sfm_ba_schur_build(sfm_handle h, sfm_ba_problem p, double alpha) 
     sfm_prof_begin(h, SFM_PROF_SCHUR);
     if (p->n_items > 0) { // 8 groups x ceil(largest group / 4) workgroups
       sfm_prof_begin(h, SFM_PROF_SCHUR_ITEMS);
-      hipLaunchKernelGGL((k_schur_items<DD, double, GG>), dim3(8 * cdiv(p->xcd_max_items, 4)), dim3(256), 0, h->stream,
-                         p->xcd_ptr, p->xcd_items, p->item_beg, p->item_end, p->pair_k, p->pair_k2, WS(L, G), WS(L, sch_part),
-                         p->cam_idx, p->item_ptr, p->cch_ptr, C, WS(L, eobs), WS(L, cch_part));
+      // SFM_SCHUR_KPACK=0: the one-pair-per-MFMA form (K = 3 of 4 used) for comparison
+      static const bool kpack = !(getenv("SFM_SCHUR_KPACK") && getenv("SFM_SCHUR_KPACK")[0] == '0');
+auto schur_items = [&](auto kp) {
+        hipLaunchKernelGGL((k_schur_items<DD, double, GG, decltype(kp)::value>), dim3(8 * cdiv(p->xcd_max_items, 4)), dim3(256), 0, h->stream,
+                           p->xcd_ptr, p->xcd_items, p->item_beg, p->item_end, p->pair_k, p->pair_k2, WS(L, G), WS(L, sch_part),
+                           p->cam_idx, p->item_ptr, p->cch_ptr, C, WS(L, eobs), WS(L, cch_part), p->has_dup ? 0 : 1);
+      };
+      if (kpack) schur_items(std::true_type{}); else schur_items(std::false_type{});
       sfm_prof_end(h, SFM_PROF_SCHUR_ITEMS);
     }
+    if (p->has_dup && p->n_cchunks > 0)        // the chunk partials of sum_k G_k e_j by the camera-wise pass over G
+      hipLaunchKernelGGL((k_cam_reduce_chunks<DD, double, GG>), dim3((unsigned)p->n_cchunks), dim3(256), 0, h->stream, p->cch_beg,
+                         p->cch_end, p->cam_obs, p->pt_idx, WS(L, G), WS(L, e), WS(L, cch_part));
     hipLaunchKernelGGL(k_schur_assemble<DD>, dim3(C, cdiv(C, 2)), dim3(256), 0, h->stream, C, p->item_ptr,
                        WS(L, sch_part), WS(L, B), WS(L, red_S));
-    // the chunk partials of sum_k G_k e_j came out of the diagonal-block items above
+    // the chunk partials of sum_k G_k e_j came out of the diagonal-block items above (or of the pass just launched)
     hipLaunchKernelGGL(k_cam_reduce_final<DD>, dim3(cdiv(n, 256)), dim3(256), 0, h->stream, C, p->cch_ptr,
                        WS(L, cch_part), WS(L, gc), WS(L, red_S) + (size_t)n * n);
     sfm_prof_end(h, SFM_PROF_SCHUR);
@@ -1234,7 +1277,7 @@ enum { CGS_RR0 = 0, CGS_RR = 1, CGS_ITER = 2, CGS_FAIL = 3, CGS_DONE = 4,
 // E_c = chol(S_cc + alpha I); Einv[c] = E_c^-1 (lower, zeros above).  One thread per camera.
 template <int D>
 __global__ void k_diag_einv(int C, const double* __restrict__ S, int n, double alpha, double* __restrict__ Einv,
-                            double* __restrict__ scal) {
+                            double* __restrict__ Efac /* E_c itself (lower), for warm starts: x~ = E^T y */, double* __restrict__ scal) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= C) return;
   double L[D][D], X[D][D];
@@ -1247,7 +1290,10 @@ __global__ void k_diag_einv(int C, const double* __restrict__ S, int n, double a
 #pragma unroll
   for (int i = 0; i < D; ++i)
 #pragma unroll
-    for (int j = 0; j < D; ++j) Einv[(size_t)c * D * D + i * D + j] = X[i][j];
+    for (int j = 0; j < D; ++j) {
+      Einv[(size_t)c * D * D + i * D + j] = X[i][j];
+      Efac[(size_t)c * D * D + i * D + j] = j <= i ? L[i][j] : 0.0;
+    }
   if (bad) scal[CGS_FAIL] = 1.0;
 }
 // St[c][c2] = Einv_c (S[c][c2] + alpha [c == c2]) Einv_c2^T, one workgroup (128 threads) per block pair, both triangles
@@ -1291,6 +1337,11 @@ __global__ void k_block_mv(int C, const double* __restrict__ Einv, const double*
 #pragma unroll
   for (int k = 0; k < D; ++k) t += (transpose ? E[k * D + a] : E[a * D + k]) * v[c * D + k];
   out[i] = sgn * t;
+}
+// out = a - delta * b (b may be null)
+__global__ void k_taylor(int n, const double* __restrict__ a, const double* __restrict__ b, double delta, double* __restrict__ out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = a[i] - (b ? delta * b[i] : 0.0);
 }
 // state 0 of the recurrence: x = 0, r = p = rhs; rr0
 __global__ __launch_bounds__(256) void k_cgs_init(int n, const double* __restrict__ rhs, double* __restrict__ x,
@@ -1392,9 +1443,211 @@ __global__ __launch_bounds__(256) void k_cgs_iter(int n, int it, double rtol2, c
   if (tid < ROWS && row0 + tid < n) out[2 * n + row0 + tid] = (s_row[tid][0] + s_row[tid][1]) + (s_row[tid][2] + s_row[tid][3]);
 }
 
+// ------------------------------------------------------------------------------------ persistent form of the same CG
+// ONE launch per system instead of one per iteration (k_cgs_iter above: ~7 us per iteration, of which the kernel boundary
+// and the re-read of S~ from L2 are most).  Workgroup b owns the PR_ROWS rows [8 b, 8 b + 8) of S~ and holds them IN
+// REGISTERS for the whole solve (thread t: the columns 2t + 512 c, c < NC -> 8 x NC x 2 doubles = 128 VGPRs at n = 2048:
+// the kernel runs one wave per SIMD), together with its columns of x, r, p.  Per iteration a workgroup multiplies its rows
+// with p (64 FMAs per thread, wave sums, four partials through LDS: fixed order), PUBLISHES its 8 entries of S~ p and
+// GATHERS all n of them: the all-gather is the only exchange between workgroups.  It uses self-validating 8-byte granules
+// (cdna_hip_programming.md, Guideline 16, form R2: {tag, 32-bit half of the double} written by ONE relaxed agent-scope
+// atomic store = global_store_dwordx2 sc1, polled with relaxed agent-scope atomic loads = sc1: no flag, no fence; a double
+// is two granules).  tag = salt (a per-launch counter: no hipGraph replay here) * 256 + iteration + 1, two slots by
+// iteration parity: a workgroup can be at most one iteration ahead of the slowest (its product of iteration i + 1 needs
+// every entry of iteration i), so when it overwrites slot i & 1 with iteration i + 2 everybody has read iteration i.
+// The vector recurrences and the two dot products are then computed REDUNDANTLY by every workgroup from identical data in
+// identical order (block sums), so all take the same branch at the same iteration and no second exchange is needed.
+// Placement-independent: nothing assumes a dispatch order or a workgroup -> XCD map; every spin is bounded, a workgroup that
+// gives up posts the launch's salt in the abort word, which the others poll beside their granules, and the host then takes
+// the per-launch kernel (and stops using this one for the handle: a grid that is not co-resident - CUs taken by another
+// process - would pay the timeout on every solve otherwise).
+constexpr int PR_ROWS = 8;
+constexpr int PR_MAX_N = 2048;                    // 8 rows x 2048 columns per workgroup in registers; grid = n / 8 <= 256
+constexpr unsigned PR_SPIN_LIMIT = 1u << 17;      // passes over a thread's granules (~1 us each) before giving up
+typedef unsigned long long pr_u64;
+#define PR_RLX_AGENT __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT
+
+template <int NC>
+__global__ __launch_bounds__(256, 1) void k_cgs_persist(int n, double rtol2, int max_iter, unsigned salt,
+                                                        const double* __restrict__ St, const double* __restrict__ rhs,
+                                                        const double* __restrict__ x0 /* may be null: start from 0 */,
+                                                        double* __restrict__ x_out, pr_u64* mail /* [2][n][2] granules */,
+                                                        pr_u64* abort_w, double* __restrict__ scal) {
+  __shared__ double s_part[PR_ROWS][4];
+  __shared__ double s_red[4];
+  __shared__ int s_ok[4];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int row0 = (int)blockIdx.x * PR_ROWS;
+  // this thread's slice of the workgroup's rows: registers for the whole solve
+  double2 sv[PR_ROWS][NC];
+#pragma unroll
+  for (int q = 0; q < PR_ROWS; ++q)
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+      const int row = row0 + q, col = 2 * tid + 512 * c;            // n is even: col < n implies col + 1 < n
+      sv[q][c] = (row < n && col < n) ? *(const double2*)(St + (size_t)row * n + col) : make_double2(0.0, 0.0);
+    }
+  double xv[2 * NC], rv[2 * NC], pv[2 * NC];
+#pragma unroll
+  for (int c = 0; c < NC; ++c) {
+    const int col = 2 * tid + 512 * c;
+    const bool in = col < n;
+    rv[2 * c] = in ? rhs[col] : 0.0; rv[2 * c + 1] = in ? rhs[col + 1] : 0.0;
+    xv[2 * c] = (in && x0) ? x0[col] : 0.0; xv[2 * c + 1] = (in && x0) ? x0[col + 1] : 0.0;
+  }
+  double rr0;
+  {
+    double t = 0.0;
+#pragma unroll
+    for (int i = 0; i < 2 * NC; ++i) t += rv[i] * rv[i];
+    rr0 = block_sum256(t, s_red);                 // ||rhs||^2 (every thread gets it): the tolerance is relative to the right-hand side
+  }
+
+  // one round: y = S~ v for this workgroup's rows, published and gathered; returns false when the launch is abandoned
+  double yv[2 * NC];
+  auto exchange = [&](const double (&v)[2 * NC], int round) -> bool {
+    double acc[PR_ROWS];
+#pragma unroll
+    for (int q = 0; q < PR_ROWS; ++q) {
+      double t = 0.0;
+#pragma unroll
+      for (int c = 0; c < NC; ++c) t += sv[q][c].x * v[2 * c] + sv[q][c].y * v[2 * c + 1];
+      acc[q] = t;
+    }
+#pragma unroll
+    for (int q = 0; q < PR_ROWS; ++q) {
+      const double t = wave_sum(acc[q]);
+      if (lane == 0) s_part[q][w] = t;
+    }
+    __syncthreads();
+    const unsigned tag = salt * 256u + (unsigned)round + 1u;
+    pr_u64* slot = mail + (size_t)(round & 1) * 2 * n;
+    if (tid < PR_ROWS && row0 + tid < n) {
+      const double y = (s_part[tid][0] + s_part[tid][1]) + (s_part[tid][2] + s_part[tid][3]);
+      const pr_u64 bits = (pr_u64)__double_as_longlong(y);
+      __hip_atomic_store(slot + 2 * (size_t)(row0 + tid), ((pr_u64)tag << 32) | (bits & 0xFFFFFFFFull), PR_RLX_AGENT);
+      __hip_atomic_store(slot + 2 * (size_t)(row0 + tid) + 1, ((pr_u64)tag << 32) | (bits >> 32), PR_RLX_AGENT);
+    }
+    // gather this thread's columns: 4 granules per chunk (two doubles), re-read until every tag matches
+    bool ok = false;
+    for (unsigned spins = 0; spins < PR_SPIN_LIMIT; ++spins) {
+      pr_u64 g[4 * NC];
+#pragma unroll
+      for (int c = 0; c < NC; ++c) {
+        const int col = 2 * tid + 512 * c;
+        const pr_u64* gp = slot + 2 * (size_t)(col < n ? col : 0);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) g[4 * c + i] = __hip_atomic_load(gp + i, PR_RLX_AGENT);
+      }
+      bool all = true;
+#pragma unroll
+      for (int c = 0; c < NC; ++c) {
+        const bool in = 2 * tid + 512 * c < n;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) all &= !in || (unsigned)(g[4 * c + i] >> 32) == tag;
+        yv[2 * c] = in ? __longlong_as_double((long long)((g[4 * c] & 0xFFFFFFFFull) | (g[4 * c + 1] << 32))) : 0.0;
+        yv[2 * c + 1] = in ? __longlong_as_double((long long)((g[4 * c + 2] & 0xFFFFFFFFull) | (g[4 * c + 3] << 32))) : 0.0;
+      }
+      if (__all(all)) { ok = true; break; }
+      if ((spins & 31u) == 31u && __hip_atomic_load(abort_w, PR_RLX_AGENT) == (pr_u64)salt) break;     // somebody gave up
+      __builtin_amdgcn_s_sleep(2);
+    }
+    if (lane == 0) s_ok[w] = ok ? 1 : 0;
+    __syncthreads();
+    const bool all_ok = (s_ok[0] & s_ok[1] & s_ok[2] & s_ok[3]) != 0;
+    __syncthreads();                                // s_part / s_ok are rewritten by the next round
+    if (!all_ok && tid == 0) __hip_atomic_store(abort_w, (pr_u64)salt, PR_RLX_AGENT);
+    return all_ok;
+  };
+  // done: 1 = the recurrence ended (converged, or broken: fail 2), 0 = out of iterations, -1 = the launch was abandoned.
+  // CGS_FAIL may already hold k_diag_einv's 1 (a diagonal block is not positive definite): it is only ever raised here.
+  auto finish = [&](double rr, int it, double done, double fail) {
+    if (blockIdx.x != 0) return;
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+      const int col = 2 * tid + 512 * c;
+      if (col < n) { x_out[col] = xv[2 * c]; x_out[col + 1] = xv[2 * c + 1]; }
+    }
+    if (tid == 0) {
+      scal[CGS_RR0] = rr0; scal[CGS_RR] = rr; scal[CGS_ITER] = (double)it; scal[CGS_DONE] = done;
+      if (fail != 0.0 && scal[CGS_FAIL] == 0.0) scal[CGS_FAIL] = fail;
+    }
+  };
+
+  int round = 0;
+  if (x0) {                                         // warm start: r = rhs - S~ x0 (one more round of the same exchange)
+    if (!exchange(xv, round++)) { finish(rr0, 0, -1.0, 0.0); return; }
+#pragma unroll
+    for (int i = 0; i < 2 * NC; ++i) rv[i] -= yv[i];
+  }
+  double rr;
+  {
+    double t = 0.0;
+#pragma unroll
+    for (int i = 0; i < 2 * NC; ++i) { pv[i] = rv[i]; t += rv[i] * rv[i]; }
+    rr = block_sum256(t, s_red);
+  }
+  if (!(rr0 > 0.0)) {                               // zero right-hand side: x = 0; NaN / Inf in it: not a system CG can solve (fail 2 ->
+    if (rr0 == 0.0) {                               // the caller's factorisation route reports the non-finite step)
+#pragma unroll
+      for (int i = 0; i < 2 * NC; ++i) xv[i] = 0.0;
+      finish(0.0, 0, 1.0, 0.0);
+    } else finish(rr0, 0, 1.0, 2.0);
+    return;
+  }
+  int it = 0;
+  for (; it < max_iter; ++it) {
+    if (rr <= rtol2 * rr0) { finish(rr, it, 1.0, 0.0); return; }
+    if (!exchange(pv, round++)) { finish(rr, it, -1.0, 0.0); return; }
+    double t = 0.0;
+#pragma unroll
+    for (int i = 0; i < 2 * NC; ++i) t += pv[i] * yv[i];
+    const double pAp = block_sum256(t, s_red);
+    if (!(pAp > 0.0)) { finish(rr, it, 1.0, 2.0); return; }       // non-positive curvature (or NaN): S~ is not positive definite
+    const double a = rr / pAp;
+    double t2 = 0.0;
+#pragma unroll
+    for (int i = 0; i < 2 * NC; ++i) { xv[i] += a * pv[i]; rv[i] -= a * yv[i]; t2 += rv[i] * rv[i]; }
+    const double rr_new = block_sum256(t2, s_red);
+    const double beta = rr_new / rr;
+#pragma unroll
+    for (int i = 0; i < 2 * NC; ++i) pv[i] = rv[i] + beta * pv[i];
+    rr = rr_new;
+  }
+  finish(rr, it, rr <= rtol2 * rr0 ? 1.0 : 0.0, 0.0);
+}
+
 // x~ = S~^-1 rhs~ by CG; returns 0 converged / 1 not converged or broken (caller falls back to the factorisation)
+// x0_t: optional start vector (warm start; only the persistent kernel takes it).  mail: 4 n doubles of granule slots.
 static int cgs_solve(sfm_ctx* h, int n, const double* St, const double* rhs_t, double* x_t, double* vec, double* scal,
-                     double rtol, int* iters_out, int* status) {
+                     double rtol, int* iters_out, int* status, const double* x0_t = nullptr, double* mail = nullptr) {
+  const double rtol2 = rtol * rtol;
+  *status = 1;
+  // ---- one persistent launch per system (k_cgs_persist); SFM_CGS_PERSIST=0 keeps the launch-per-iteration kernel
+  if (mail && n <= PR_MAX_N && !h->cgs_persist_off) {
+    const char* pe = getenv("SFM_CGS_PERSIST");
+    if (!(pe && pe[0] == '0')) {
+      const unsigned grid = (unsigned)cdiv(n, PR_ROWS);
+      const int nc = (int)cdiv(n, 512);
+      pr_u64* abort_w = (pr_u64*)(scal + 12);
+      h->cgs_seq = (h->cgs_seq + 1u) & 0xFFFFFFu;
+      if (h->cgs_seq == 0u) h->cgs_seq = 1u;           // tag 0 is what zeroed memory reads as
+      const unsigned salt = h->cgs_seq;
+#define PR_LAUNCH(NC) hipLaunchKernelGGL((k_cgs_persist<NC>), dim3(grid), dim3(256), 0, h->stream, n, rtol2, CGS_MAX_ITER, salt, St, rhs_t, x0_t, x_t, (pr_u64*)mail, abort_w, scal)
+      if (nc <= 1) PR_LAUNCH(1); else if (nc == 2) PR_LAUNCH(2); else if (nc == 3) PR_LAUNCH(3); else PR_LAUNCH(4);
+#undef PR_LAUNCH
+      SFM_HIP(h, hipMemcpyAsync(h->pinned, scal, 8 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+      SFM_HIP(h, hipStreamSynchronize(h->stream));
+      SFM_LAUNCH_CHECK(h, "cgs_solve (persistent)");
+      if (h->pinned[CGS_DONE] != -1.0) {               // -1: the launch was abandoned (a spin ran out) - fall through
+        *iters_out += (int)h->pinned[CGS_ITER];
+        if (h->pinned[CGS_FAIL] == 0.0 && h->pinned[CGS_DONE] != 0.0) *status = 0;
+        return SFM_OK;
+      }
+      h->cgs_persist_off = 1;
+      fprintf(stderr, "sfm_amd: the persistent CG launch was abandoned (grid not co-resident?); using one launch per iteration from now on\n");
+    }
+  }
   // (column chunks per thread, rows per workgroup): 128 registers of prefetched matrix per thread in the two larger shapes
   // four rows per workgroup: at n = 2000 that is 512 workgroups (two per CU) - 8 rows / 256 workgroups measured 6 % slower per
   // iteration, 2 rows / 1,024 workgroups 9 % slower (twice the redundant vector work).  SFM_CGS_ROWS=8 restores the old shapes.
@@ -1406,8 +1659,6 @@ static int cgs_solve(sfm_ctx* h, int n, const double* St, const double* rhs_t, d
   const unsigned grid = 8u * (unsigned)per_xcd_wg;
   hipLaunchKernelGGL(k_cgs_init, dim3(1), dim3(256), 0, h->stream, n, rhs_t, x_t, vec, vec + n, scal);
   int it = 0;
-  *status = 1;
-  const double rtol2 = rtol * rtol;
   int batch = 13;                                                  // launch 0 only multiplies: first look after 12 iterations
   while (it <= CGS_MAX_ITER) {
     for (int b = 0; b < batch; ++b, ++it)
@@ -1451,15 +1702,33 @@ extern "C" int sfm_ba_schur_solve(sfm_handle h, sfm_ba_problem p, double alpha, 
     sfm_prof_begin(h, SFM_PROF_CHOL);
     SFM_HIP(h, hipMemsetAsync(WS(L, cg_scal), 0, 16 * sizeof(double), h->stream));
     DISPATCH_D(D, {
-      hipLaunchKernelGGL(k_diag_einv<DD>, dim3(cdiv(C, 64)), dim3(64), 0, h->stream, C, S, n, alpha, WS(L, cg_Minv), WS(L, cg_scal));
+      hipLaunchKernelGGL(k_diag_einv<DD>, dim3(cdiv(C, 64)), dim3(64), 0, h->stream, C, S, n, alpha, WS(L, cg_Minv), WS(L, cg_M), WS(L, cg_scal));
       hipLaunchKernelGGL(k_scale_system<DD>, dim3(C, C), dim3(128), 0, h->stream, n, S, alpha, WS(L, cg_Minv), dw.Lm);
       hipLaunchKernelGGL(k_block_mv<DD>, dim3(cdiv(n, 256)), dim3(256), 0, h->stream, C, WS(L, cg_Minv), S + (size_t)n * n, WS(L, cg_r), 0, 1.0);
     });
     int status = 1;
-    rc = cgs_solve(h, n, dw.Lm, WS(L, cg_r), WS(L, cg_z), dw.LmT, WS(L, cg_scal), CGS_RTOL, &p->cg_iters, &status); if (rc) return rc;
+    // Warm start (persistent kernel only).  Inside More's iteration consecutive damped systems differ only in alpha, and
+    // dp/dalpha = -(H + alpha I)^-1 p = -q is what the previous solve's second system produced: p_c(alpha') ~ p_c(alpha) -
+    // (alpha' - alpha) q_c(alpha), second-order accurate.  In the scaled variables x~_0 = E'^T y_0 with y_0 = -p_c.
+    double* warm = WS(L, cg_warm);                    // [pc_prev | qc_prev | x0 | scratch]
+    const double* x0 = nullptr;
+    static const bool warm_on = !(getenv("SFM_CGS_WARM") && getenv("SFM_CGS_WARM")[0] == '0');
+    if (warm_on && p->warm_pc_ok && std::fabs(alpha - p->warm_alpha) <= 0.5 * p->warm_alpha) {
+      hipLaunchKernelGGL(k_taylor, dim3(cdiv(n, 256)), dim3(256), 0, h->stream, n, warm, p->warm_qc_ok ? warm + n : (const double*)nullptr,
+                         alpha - p->warm_alpha, warm + 3 * (size_t)n);
+      DISPATCH_D(D, hipLaunchKernelGGL(k_block_mv<DD>, dim3(cdiv(n, 256)), dim3(256), 0, h->stream, C, WS(L, cg_M), warm + 3 * (size_t)n,
+                                       warm + 2 * (size_t)n, 1, -1.0));          // x~_0 = E^T (-p_c guess)
+      x0 = warm + 2 * (size_t)n;
+    }
+    p->warm_pc_ok = p->warm_qc_ok = 0;
+    rc = cgs_solve(h, n, dw.Lm, WS(L, cg_r), WS(L, cg_z), dw.LmT, WS(L, cg_scal), CGS_RTOL, &p->cg_iters, &status, x0, WS(L, cg_mail)); if (rc) return rc;
     if (status == 0) {
       DISPATCH_D(D, hipLaunchKernelGGL(k_block_mv<DD>, dim3(cdiv(n, 256)), dim3(256), 0, h->stream, C, WS(L, cg_Minv), WS(L, cg_z),
                                        WS(L, pc), 1, -1.0));                      // p_c = -E^-T x~
+      if (warm_on) {
+        SFM_HIP(h, hipMemcpyAsync(warm, WS(L, pc), (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+        p->warm_pc_ok = 1; p->warm_alpha = alpha;
+      }
       p->cg_state = 1;
     } else {
       p->cg_fallbacks++;
@@ -1514,9 +1783,15 @@ extern "C" int sfm_ba_finish_solve(sfm_handle h, sfm_ba_problem p, int want_q) {
       DISPATCH_D(D, hipLaunchKernelGGL(k_block_mv<DD>, dim3(cdiv(n, 256)), dim3(256), 0, h->stream, C, WS(L, cg_Minv), WS(L, tvec),
                                        WS(L, cg_r), 0, 1.0));
       status = 1;
-      rc = cgs_solve(h, n, dw.Lm, WS(L, cg_r), WS(L, cg_z), dw.LmT, WS(L, cg_scal), CGS_RTOL, &p->cg_iters, &status); if (rc) return rc;
-      if (status == 0)
+      rc = cgs_solve(h, n, dw.Lm, WS(L, cg_r), WS(L, cg_z), dw.LmT, WS(L, cg_scal), CGS_RTOL, &p->cg_iters, &status, nullptr, WS(L, cg_mail)); if (rc) return rc;
+      if (status == 0) {
         hipLaunchKernelGGL(k_dot, dim3(1), dim3(1024), 0, h->stream, n, WS(L, cg_r), WS(L, cg_z), WS(L, cg_scal) + 8);
+        if (p->warm_pc_ok) {                         // q_c = E^-T x~_2 = -dp_c/dalpha for the next system's start vector
+          DISPATCH_D(D, hipLaunchKernelGGL(k_block_mv<DD>, dim3(cdiv(n, 256)), dim3(256), 0, h->stream, C, WS(L, cg_Minv), WS(L, cg_z),
+                                           WS(L, cg_warm) + n, 1, 1.0));
+          p->warm_qc_ok = 1;
+        }
+      }
       sfm_prof_end(h, SFM_PROF_TRSV);
     }
     if (status == 0) {
@@ -1721,11 +1996,14 @@ __global__ __launch_bounds__(256) void k_finish_solve_pcg(int n, const double* _
   }
 }
 
+
+
 namespace {
 struct Pcg {
   sfm_ctx* h; sfm_ba_problem p; Lay L; double* ws; double alpha, rtol; int max_iter;
   sfm_reduce_fn reduce; void* user;
   int iters;
+  bool stalled = false;      // a system ran out of iterations above rtol
 
   int red(double* ptr, int64_t count) {
     if (!reduce) return SFM_OK;
@@ -1752,6 +2030,7 @@ struct Pcg {
     DISPATCH_D(D, hipLaunchKernelGGL(k_cg_init<DD>, dim3(1), dim3(1024), 0, h->stream, n, rhs, WS(L, cg_Minv), x, WS(L, cg_r), WS(L, cg_z),
                                      WS(L, cg_p), WS(L, cg_scal)));
     const int check_every = 8;
+    bool settled = false;                            // converged, or a failure the scalars already carry
     for (int it = 0; it < max_iter; ++it) {
       int rc = matvec(WS(L, cg_p)); if (rc) return rc;
       DISPATCH_D(D, hipLaunchKernelGGL(k_cg_step<DD>, dim3(1), dim3(1024), 0, h->stream, n, alpha, WS(L, cg_Ap), WS(L, cg_p), x, WS(L, cg_r),
@@ -1761,15 +2040,49 @@ struct Pcg {
         SFM_HIP(h, hipMemcpyAsync(h->pinned, WS(L, cg_scal), 8 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
         SFM_HIP(h, hipStreamSynchronize(h->stream));
         const double rr = h->pinned[CG_RR], rr0 = h->pinned[CG_RR0];
-        if (h->pinned[CG_FAIL] != 0.0 || !(rr == rr)) break;               // reported through the scalars
-        if (rr <= rtol * rtol * rr0) break;
+        if (h->pinned[CG_FAIL] != 0.0 || !(rr == rr)) { settled = true; break; }     // reported through the scalars
+        if (rr <= rtol * rtol * rr0) { settled = true; break; }
       }
+    }
+    // max_iter iterations without reaching rtol (the last look above was at it + 1 == max_iter): an inexact p and
+    // p^T (H + alpha I)^-1 p would silently steer More's alpha update.  Measured on the goldens: near convergence of the
+    // outer loop (alpha ~ 1e-3, S nearly singular along the 7 gauge directions) block-Jacobi PCG stalls at a relative
+    // residual of 1e-2 .. 1e-4.  The caller (sfm_ba_solve_pcg) then solves THIS damped system by the formed-S route, as the
+    // explicit-S CG falls back to its factorisation.
+    if (!settled) {
+      const double rr = h->pinned[CG_RR], rr0 = h->pinned[CG_RR0];
+      const double rel = rr0 > 0.0 ? std::sqrt(rr / rr0) : 0.0;
+      if (rel > p->pcg_worst_relres) p->pcg_worst_relres = rel;
+      if (getenv("SFM_PCG_DEBUG")) fprintf(stderr, "sfm_amd pcg: alpha %.3e: %d iterations, relative residual %.3e (rtol %.1e): formed-S fallback\n", alpha, max_iter, rel, rtol);
+      stalled = true;
     }
     SFM_LAUNCH_CHECK(h, "sfm_ba_solve_pcg");
     return SFM_OK;
   }
 };
 }  // namespace
+
+// The damped system by the formed-S route (what the trust-region loop does with SFM_SOLVER_DENSE), for a system the
+// implicit-Schur PCG could not bring to its tolerance.
+static int pcg_fallback_dense(sfm_ctx* h, sfm_ba_problem p, const Lay& L, double alpha, int want_q, sfm_reduce_fn reduce, void* user) {
+  char* base = (char*)p->workspace;
+  sfm_ba_layout lay; sfm_ba_get_layout(p, &lay);
+  auto red = [&](int64_t off, int64_t count) -> int {
+    if (!reduce) return SFM_OK;
+    return reduce(user, base + off, count, 0) ? sfm_fail(h, SFM_ERR_HIP, "sfm_ba_solve_pcg", "the reduce hook failed") : SFM_OK;
+  };
+  int rc;
+  p->pcg_fallbacks++;
+  if ((rc = sfm_ba_schur_build(h, p, alpha))) return rc;
+  if (reduce) {
+    if ((rc = sfm_ba_pack_system(h, p))) return rc;
+    if ((rc = red(lay.reduce_Sp_off, lay.reduce_Sp_count))) return rc;
+    if ((rc = sfm_ba_unpack_system(h, p))) return rc;
+  }
+  if ((rc = sfm_ba_schur_solve(h, p, alpha, want_q))) return rc;
+  if ((rc = red(lay.reduce_q_off, lay.reduce_q_count))) return rc;
+  return sfm_ba_finish_solve(h, p, want_q);
+}
 
 extern "C" int sfm_ba_solve_pcg(sfm_handle h, sfm_ba_problem p, double alpha, int want_q, double rtol, int32_t max_iter,
                                 sfm_reduce_fn reduce, void* reduce_user, int32_t* iters_host) {
@@ -1807,6 +2120,11 @@ extern "C" int sfm_ba_solve_pcg(sfm_handle h, sfm_ba_problem p, double alpha, in
                                    WS(L, cg_scal)));
   // y = S^-1 r ; p_c = -y
   if ((rc = cg.solve(WS(L, tvec), WS(L, y)))) return rc;
+  if (cg.stalled) {
+    sfm_prof_end(h, SFM_PROF_CHOL);
+    if (iters_host) *iters_host = cg.iters;
+    return pcg_fallback_dense(h, p, L, alpha, want_q, reduce, reduce_user);
+  }
   hipLaunchKernelGGL(k_copy_neg, dim3(cdiv(n, 256)), dim3(256), 0, h->stream, WS(L, y), WS(L, pc), n, -1.0);
   sfm_prof_end(h, SFM_PROF_CHOL);
   sfm_prof_begin(h, SFM_PROF_BACKSUB);
@@ -1831,6 +2149,11 @@ extern "C" int sfm_ba_solve_pcg(sfm_handle h, sfm_ba_problem p, double alpha, in
     sfm_prof_begin(h, SFM_PROF_TRSV);
     hipLaunchKernelGGL(k_add_vec, dim3(cdiv(n, 256)), dim3(256), 0, h->stream, WS(L, pc), WS(L, red_q), WS(L, tvec), n);
     if ((rc = cg.solve(WS(L, tvec), WS(L, y)))) return rc;
+    if (cg.stalled) {
+      sfm_prof_end(h, SFM_PROF_TRSV);
+      if (iters_host) *iters_host = cg.iters;
+      return pcg_fallback_dense(h, p, L, alpha, want_q, reduce, reduce_user);
+    }
     hipLaunchKernelGGL(k_dot, dim3(1), dim3(1024), 0, h->stream, n, WS(L, tvec), WS(L, y), WS(L, cg_scal) + CG_DOT);
     sfm_prof_end(h, SFM_PROF_TRSV);
   }

@@ -5,7 +5,7 @@
 struct Lay {   // workspace offsets in doubles (regions holding float32 in mixed precision are sized in doubles too)
   int64_t recA, recB, campre, campre2, B, gc, Cp, gp, Linv, e, v, tmp3, G, eobs, red_lin, gmax, red_S, red_q,
       red_step, pc, pp, y, tvec, scalars, part_obs, part_pt, part_x, cost_reg, regrec, dense, sch_part, cch_part, cbl_part,
-      cg_r, cg_z, cg_p, cg_Ap, cg_M, cg_Minv, cg_scal, total;
+      cg_r, cg_z, cg_p, cg_Ap, cg_M, cg_Minv, cg_scal, cg_mail, cg_warm, total;
   int64_t nblk_obs, nblk_pt;
 };
 
@@ -34,7 +34,18 @@ struct sfm_ba_prob {
   // sfm_ba_schur_solve and sfm_ba_finish_solve: cg_state 1 = p_c came from CG on the scaled system (still in the
   // factor's buffer), 0 = from the factorisation
   int camera_solver, cg_state, cg_iters, cg_fallbacks;
+  // 1: some camera appears more than once on a track.  The diagonal Schur blocks then hold cross pairs besides the
+  // self-pairs, so k_schur_items must not take its fused diagonal path (one gather for both operands, right-hand side in
+  // accumulator column D): every item runs the general path and the right-hand side comes from the camera-wise pass.
+  int has_dup;
+  // sfm_ba_solve_pcg: damped solves handed to the formed-S route because a system ran out of iterations above rtol, and
+  // the worst relative residual PCG had reached in such a system
+  int64_t pcg_fallbacks;
+  double pcg_worst_relres;
   double cg_alpha;
+  // warm start of the camera CG (ba.hip, sfm_ba_schur_solve): p_c / q_c of the previous damped solve of THIS linearisation
+  int warm_pc_ok, warm_qc_ok;
+  double warm_alpha;
 };
 
 Lay ba_layout(int64_t C, int64_t P, int64_t N, int64_t D, int64_t n_items, int64_t n_cchunks, int precision);

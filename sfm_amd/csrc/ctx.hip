@@ -23,6 +23,8 @@ extern "C" int sfm_create(int device, sfm_handle* out) {
   h->profiling = 0;
   h->scratch = nullptr;
   h->scratch_bytes = 0;
+  h->cgs_seq = 0;
+  h->cgs_persist_off = 0;
   memset(h->prof, 0, sizeof(h->prof));
   if ((e = hipHostMalloc((void**)&h->pinned, SFM_SC_COUNT * sizeof(double), hipHostMallocDefault)) != hipSuccess) {
     fprintf(stderr, "sfm_create: hipHostMalloc -> %s\n", hipGetErrorString(e));

@@ -58,13 +58,17 @@ __global__ __launch_bounds__(256) void k_iota_keys(int64_t N, const int* __restr
 
 // number of pairs (k, k2) observation k starts: the k2 of its track with cam(k2) >= cam(k)
 __global__ __launch_bounds__(256) void k_pair_count(int64_t N, const int* __restrict__ cam_idx, const int* __restrict__ pt_idx,
-                                                    const int* __restrict__ pt_ptr, int* __restrict__ cnt) {
+                                                    const int* __restrict__ pt_ptr, int* __restrict__ cnt,
+                                                    int* __restrict__ dup) {
   const int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (k >= N) return;
   const int j = pt_idx[k], c = cam_idx[k];
-  int n = 0;
-  for (int k2 = pt_ptr[j]; k2 < pt_ptr[j + 1]; ++k2) n += (cam_idx[k2] >= c) ? 1 : 0;
+  int n = 0, same = 0;
+  for (int k2 = pt_ptr[j]; k2 < pt_ptr[j + 1]; ++k2) { n += (cam_idx[k2] >= c) ? 1 : 0; same += (cam_idx[k2] == c) ? 1 : 0; }
   cnt[k] = n;
+  // a camera twice on one track (the reference's dict-keyed tracks cannot produce it, the C API can): the diagonal
+  // block (c, c) then also holds the cross pairs (k_a, k_b), (k_b, k_a) - see sfm_ba_prob::has_dup
+  if (same > 1) atomicOr(dup, 1);
 }
 
 __global__ __launch_bounds__(256) void k_pair_fill(int64_t N, int C, const int* __restrict__ cam_idx,
@@ -242,7 +246,8 @@ extern "C" int sfm_ba_create_problem(sfm_handle h, const sfm_ba_desc* d, sfm_ba_
   DevBuf cnt, off;
   PB_HIP(cnt.alloc((N + 1) * 4)); PB_HIP(off.alloc((N + 1) * 8));
   PB_HIP(hipMemsetAsync(cnt.p, 0, (N + 1) * 4, st));
-  hipLaunchKernelGGL(k_pair_count, dim3(cdiv(N, 256)), dim3(256), 0, st, N, p->cam_idx, p->pt_idx, p->pt_ptr, cnt.as<int>());
+  PB_HIP(hipMemsetAsync(err, 0, 4, st));         // (checked and found 0 above) re-used as the duplicate flag
+  hipLaunchKernelGGL(k_pair_count, dim3(cdiv(N, 256)), dim3(256), 0, st, N, p->cam_idx, p->pt_idx, p->pt_ptr, cnt.as<int>(), err);
   {
     size_t sb = 0;
     PB_HIP(rocprim::exclusive_scan(nullptr, sb, cnt.as<int>(), off.as<long long>(), 0ll, (size_t)N + 1,
@@ -251,8 +256,11 @@ extern "C" int sfm_ba_create_problem(sfm_handle h, const sfm_ba_desc* d, sfm_ba_
     PB_HIP(rocprim::exclusive_scan(stmp.p, sb, cnt.as<int>(), off.as<long long>(), 0ll, (size_t)N + 1,
                                    rocprim::plus<long long>(), st));
     long long total = 0;
+    int hdup = 0;
     PB_HIP(hipMemcpyAsync(&total, off.as<long long>() + N, 8, hipMemcpyDeviceToHost, st));
+    PB_HIP(hipMemcpyAsync(&hdup, err, 4, hipMemcpyDeviceToHost, st));
     PB_HIP(hipStreamSynchronize(st));       // stmp is released after the scan has run
+    p->has_dup = hdup ? 1 : 0;
     if (total >= (1ll << 31)) { sfm_ba_destroy_problem(p); return sfm_fail(h, SFM_ERR_ARG, "sfm_ba_create_problem", "too many camera pairs for int32 indices"); }
     p->n_pairs = total;
   }
@@ -352,6 +360,12 @@ extern "C" int sfm_ba_create_problem(sfm_handle h, const sfm_ba_desc* d, sfm_ba_
 extern "C" int sfm_ba_solver_stats(sfm_ba_problem p, int64_t* cg_iters, int64_t* cg_fallbacks) {
   if (!p || !cg_iters || !cg_fallbacks) return SFM_ERR_ARG;
   *cg_iters = p->cg_iters; *cg_fallbacks = p->cg_fallbacks;
+  return SFM_OK;
+}
+
+extern "C" int sfm_ba_pcg_stats(sfm_ba_problem p, int64_t* fallbacks, double* worst_relres) {
+  if (!p || !fallbacks || !worst_relres) return SFM_ERR_ARG;
+  *fallbacks = p->pcg_fallbacks; *worst_relres = p->pcg_worst_relres;
   return SFM_OK;
 }
 

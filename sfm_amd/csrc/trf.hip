@@ -57,7 +57,7 @@ struct Backend {
     if (s->opt.solver == SFM_SOLVER_PCG) {
       const int n = s->p->n_cams * s->p->cam_dim;
       const double rtol = s->opt.pcg_rtol > 0 ? s->opt.pcg_rtol : 1e-13;
-      const int mit = s->opt.pcg_max_iter > 0 ? s->opt.pcg_max_iter : (4 * n < 20000 ? 4 * n : 20000);
+      const int mit = s->opt.pcg_max_iter > 0 ? s->opt.pcg_max_iter : 400;      // then the formed-S fallback (sfm_ba_solve_pcg)
       int32_t its = 0;
       if ((rc = sfm_ba_solve_pcg(s->h, s->p, alpha, want_q, rtol, mit, s->reduce, s->reduce_user, &its))) return rc;
       s->cg_iters += its;

@@ -89,7 +89,7 @@ template <class BE>
 int outer(BE& be, State& s, const Options& o, int* more) {
   *more = 0;
   if (o.max_outer >= 0 && s.iteration >= o.max_outer) return 0;
-  if (s.g_inf < o.gtol && o.check_tolerances && s.status < 0) s.status = 1;
+  if (s.g_inf < o.gtol && o.check_tolerances) s.status = 1;       // overrides an ftol / xtol status of the same iteration, as scipy trf.py:451-453 does
   if (s.status >= 0 || s.nfev == o.max_nfev) return 0;
   double actual = -1.0, cost_new = s.cost, xnew_norm = s.x_norm;
   int rc;

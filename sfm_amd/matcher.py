@@ -152,13 +152,9 @@ def _pinned_stage(n_bytes):
     return buf
 
 
-def _prepare_sets(descs, metric, dev, h):
-    """Descriptor sets of several images -> one device array (rows back to back), its row offsets and the metric code.
-    Same dtype rules as knn2: float32 sets whose values are all integers in [0,255] go to the exact uint8 path."""
+def _upload_sets(arrs, dev):
+    """Descriptor sets of several images -> one device array (rows back to back) and its row offsets."""
     import torch
-    arrs = [np.ascontiguousarray(d) for d in descs]
-    if not arrs:
-        raise ValueError("no descriptor sets")
     dim = arrs[0].shape[1]
     if any(a.ndim != 2 or a.shape[1] != dim or a.dtype != arrs[0].dtype for a in arrs):
         raise ValueError("descriptor sets must be [n, dim] arrays of one dtype and dim")
@@ -173,53 +169,17 @@ def _prepare_sets(descs, metric, dev, h):
         np.concatenate(arrs, axis=0, out=host)
     allrows = torch.from_numpy(host).to(dev, non_blocking=True)
     torch.cuda.current_stream(dev).synchronize()          # the staging buffer is reused by the next call
-    metric = _resolve_metric(allrows, allrows, metric)
-    if metric == "hamming":
-        if allrows.dtype != torch.uint8:
-            raise ValueError("hamming needs uint8 descriptors")
-        return allrows, ptr, _lib.METRIC_HAMMING, dim
-    if allrows.dtype == torch.uint8:
-        if dim in (32, 64, 128):
-            return allrows, ptr, _lib.METRIC_L2_U8, dim
-        return allrows.float(), ptr, _lib.METRIC_L2_F32, dim
-    allrows = allrows.float()
-    if dim in (32, 64, 128):
-        flag = torch.ones(1, dtype=torch.int32, device=dev)
-        a8 = torch.empty(allrows.shape, dtype=torch.uint8, device=dev)
-        h.call("sfm_match_f32_to_u8", C.c_void_p(allrows.data_ptr()), allrows.numel(), C.c_void_p(a8.data_ptr()),
-               C.c_void_p(flag.data_ptr()))
-        if int(flag.item()) == 1:
-            return a8, ptr, _lib.METRIC_L2_U8, dim
-    return allrows, ptr, _lib.METRIC_L2_F32, dim
+    return allrows, ptr, dim
 
 
-def match_pairs(descs, pairs, ratio=0.75, metric="auto", device=0):
-    """match_features for MANY image pairs in one launch (sfm_match_knn2_batched + sfm_match_ratio_batched).
-
-    descs: list of per-image descriptor arrays; pairs: list of (i, j) = match image i's descriptors (queries)
-    against image j's (train), exactly what the reference does once per pair in its serial loop
-    (find_matches.py:329-350, call at :272).  Returns one (queryIdx, trainIdx, distance) triple of NumPy arrays
-    per pair, each bit-identical to match_arrays(descs[i], descs[j]).  Pairs with an empty side yield empty
-    arrays; a pair whose train image has exactly one descriptor raises like the reference's unpacking (:151)."""
+def _run_batch(h, dev, rows, ptr, code, dim, seg_pairs, ratio):
+    """One sfm_match_knn2_batched + sfm_match_ratio_batched over the image pairs `seg_pairs` (indices into ptr)."""
     import torch
-    empty = (np.zeros(0, np.int32), np.zeros(0, np.int32), np.zeros(0, np.float32))
-    pairs = [(int(i), int(j)) for i, j in pairs]
-    sizes = [int(np.asarray(d).shape[0]) for d in descs]
-    for i, j in pairs:
-        if sizes[i] > 0 and sizes[j] == 1:
-            raise ValueError("not enough values to unpack (expected 2, got 1)")
-    live = [s for s, (i, j) in enumerate(pairs) if sizes[i] > 0 and sizes[j] >= 2]
-    out = [empty] * len(pairs)
-    if not live:
-        return out
-    h = _lib.get_handle(device)
-    dev = torch.device("cuda", device)
-    rows, ptr, code, dim = _prepare_sets(descs, metric, dev, h)
-    n_seg = len(live)
-    q_beg = np.array([ptr[pairs[s][0]] for s in live], dtype=np.int64)
-    q_end = np.array([ptr[pairs[s][0] + 1] for s in live], dtype=np.int64)
-    t_beg = np.array([ptr[pairs[s][1]] for s in live], dtype=np.int64)
-    t_end = np.array([ptr[pairs[s][1] + 1] for s in live], dtype=np.int64)
+    n_seg = len(seg_pairs)
+    q_beg = np.array([ptr[i] for i, _ in seg_pairs], dtype=np.int64)
+    q_end = np.array([ptr[i + 1] for i, _ in seg_pairs], dtype=np.int64)
+    t_beg = np.array([ptr[j] for _, j in seg_pairs], dtype=np.int64)
+    t_end = np.array([ptr[j + 1] for _, j in seg_pairs], dtype=np.int64)
     hp = lambda a: C.c_void_p(a.ctypes.data)
     n_out, need = C.c_int64(), C.c_int64()
     n_rows = int(rows.shape[0])
@@ -244,9 +204,71 @@ def match_pairs(descs, pairs, ratio=0.75, metric="auto", device=0):
     sp = seg_ptr.cpu().numpy()
     m = int(sp[-1])
     qh, th, dh = qi[:m].cpu().numpy(), ti[:m].cpu().numpy(), dd[:m].cpu().numpy()
-    for k, s in enumerate(live):
-        a, b = int(sp[k]), int(sp[k + 1])
-        out[s] = (qh[a:b], th[a:b], dh[a:b])       # disjoint views of the three result arrays (444 copies were 0.25 ms of a 1.2 ms call)
+    # disjoint views of the three result arrays (444 copies were 0.25 ms of a 1.2 ms call)
+    return [(qh[int(sp[k]):int(sp[k + 1])], th[int(sp[k]):int(sp[k + 1])], dh[int(sp[k]):int(sp[k + 1])]) for k in range(n_seg)]
+
+
+def match_pairs(descs, pairs, ratio=0.75, metric="auto", device=0):
+    """match_features for MANY image pairs in one launch (sfm_match_knn2_batched + sfm_match_ratio_batched).
+
+    descs: list of per-image descriptor arrays (None = an image without keypoints, as cv2 returns it); pairs: list of
+    (i, j) = match image i's descriptors (queries) against image j's (train), exactly what the reference does once per
+    pair in its serial loop (find_matches.py:329-350, call at :272).  Returns one entry per pair, each what
+    match_arrays(descs[i], descs[j]) gives for THAT pair: a (queryIdx, trainIdx, distance) triple of NumPy arrays, bit
+    for bit - empty arrays for a pair with an empty side, and the ValueError of the reference's unpacking (:151) AS THE
+    ENTRY (not raised) for a pair whose train image has exactly one descriptor: the reference's per-pair try / except
+    (:344-350) skips that pair only.  Only images some live pair refers to are uploaded.  The exact uint8 path is decided
+    per image: float32 sets whose values are all integers in [0, 255] pair up on the matrix cores, pairs touching any
+    other float set run the float32 kernel (one launch per group; on integer-valued rows both kernels give the same bits:
+    sums below 2^24 are exact in float32)."""
+    import torch
+    empty = (np.zeros(0, np.int32), np.zeros(0, np.int32), np.zeros(0, np.float32))
+    pairs = [(int(i), int(j)) for i, j in pairs]
+    sizes = [0 if d is None else int(np.asarray(d).shape[0]) for d in descs]
+    out = [empty] * len(pairs)
+    live = []
+    for s, (i, j) in enumerate(pairs):
+        if sizes[i] > 0 and sizes[j] == 1:
+            out[s] = ValueError("not enough values to unpack (expected 2, got 1)")
+        elif sizes[i] > 0 and sizes[j] >= 2:
+            live.append(s)
+    if not live:
+        return out
+    h = _lib.get_handle(device)
+    dev = torch.device("cuda", device)
+    used = sorted({i for s in live for i in pairs[s]})
+    slot = {img: k for k, img in enumerate(used)}
+    rows, ptr, dim = _upload_sets([np.ascontiguousarray(descs[i]) for i in used], dev)
+    metric = _resolve_metric(rows, rows, metric)
+    seg = [(slot[pairs[s][0]], slot[pairs[s][1]]) for s in live]
+    groups = []                                            # (rows, metric code, positions in `live`)
+    if metric == "hamming":
+        if rows.dtype != torch.uint8:
+            raise ValueError("hamming needs uint8 descriptors")
+        groups.append((rows, _lib.METRIC_HAMMING, list(range(len(live)))))
+    elif rows.dtype == torch.uint8:
+        groups.append((rows, _lib.METRIC_L2_U8, list(range(len(live)))) if dim in (32, 64, 128)
+                      else (rows.float(), _lib.METRIC_L2_F32, list(range(len(live)))))
+    else:
+        rows = rows.float()
+        if dim in (32, 64, 128):
+            # per image: every value an integer in [0, 255]?  (what SIFT emits)
+            row_ok = ((rows == rows.round()) & (rows >= 0) & (rows <= 255)).all(dim=1)
+            csum = torch.zeros(rows.shape[0] + 1, dtype=torch.int64, device=dev)
+            torch.cumsum(row_ok.to(torch.int64), 0, out=csum[1:])
+            tp = torch.from_numpy(ptr).to(dev)
+            img_ok = ((csum[tp[1:]] - csum[tp[:-1]]) == (tp[1:] - tp[:-1])).cpu().numpy()
+            exact = [k for k, (a, b) in enumerate(seg) if img_ok[a] and img_ok[b]]
+            other = [k for k, (a, b) in enumerate(seg) if not (img_ok[a] and img_ok[b])]
+            if exact:
+                groups.append((rows.to(torch.uint8), _lib.METRIC_L2_U8, exact))     # rows of other images are never read by this group
+            if other:
+                groups.append((rows, _lib.METRIC_L2_F32, other))
+        else:
+            groups.append((rows, _lib.METRIC_L2_F32, list(range(len(live)))))
+    for grows, code, pos in groups:
+        for k, res in zip(pos, _run_batch(h, dev, grows, ptr, code, dim, [seg[k] for k in pos], ratio)):
+            out[live[k]] = res
     return out
 
 
@@ -267,6 +289,15 @@ class ImageMatcher(VerificationMixin):
 
     def match_features_batched(self, descs, pairs):
         """match_features(descs[i], descs[j]) for every (i, j) of `pairs` in one launch: the list the reference's
-        pair loop (find_matches.py:329-350) would have collected call by call."""
-        return [[DMatch(a, b, c) for a, b, c in zip(q.tolist(), t.tolist(), d.tolist())]
-                for q, t, d in match_pairs(descs, pairs, self.ratio, self.metric, self.device)]
+        pair loop (find_matches.py:329-350) would have collected call by call.  A pair the reference's per-pair
+        try / except (:344-350) would have logged and skipped (one train descriptor) is logged and yields None."""
+        import logging
+        out = []
+        for (i, j), res in zip(pairs, match_pairs(descs, pairs, self.ratio, self.metric, self.device)):
+            if isinstance(res, Exception):
+                logging.error(f"Error processing pair ({i}, {j}): {res}")
+                out.append(None)
+                continue
+            q, t, d = res
+            out.append([DMatch(a, b, c) for a, b, c in zip(q.tolist(), t.tolist(), d.tolist())])
+        return out

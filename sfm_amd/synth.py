@@ -45,9 +45,28 @@ class Scene:
         return poses, self.pts0.tolist(), tracks, self.K.copy()
 
 
+def coherent_camera_order(centres):
+    """Permutation that numbers cameras on the hemisphere so that neighbours in index are neighbours in space: latitude
+    rings, serpentine in azimuth - the order a turntable / orbit capture adds its images in (the reference's shipped bunny
+    set: 36 views around the object, tracks between neighbouring views only)."""
+    n = centres.shape[0]
+    z = centres[:, 2] / np.linalg.norm(centres, axis=1)
+    n_rings = max(1, int(round(np.sqrt(n / 2.0))))
+    ring = np.minimum((np.argsort(np.argsort(z)) * n_rings) // n, n_rings - 1)
+    phi = np.arctan2(centres[:, 1], centres[:, 0])
+    key = np.where(ring % 2 == 0, phi, -phi)
+    return np.lexsort((key, ring))
+
+
 def make_scene(n_cams, n_pts, obs_per_point=None, seed=0, noise_px=0.5,
-               pt_sigma=0.02, cam_sigma=0.0, radius=6.0):
-    """Synthetic pinhole scene.  obs_per_point=None -> every camera sees every point."""
+               pt_sigma=0.02, cam_sigma=0.0, radius=6.0, visibility="random"):
+    """Synthetic pinhole scene.  obs_per_point=None -> every camera sees every point.
+    visibility="random": the L cameras of a track are drawn uniformly (the BASELINE scene).
+    visibility="nearest": spatially coherent, as a real capture is - the points lie on the surface of the unit sphere
+    and each is seen by the L cameras whose centres are closest in direction, and the cameras are numbered along the
+    hemisphere (coherent_camera_order)."""
+    if visibility not in ("random", "nearest"):
+        raise ValueError(f"unknown visibility {visibility!r}")
     rng = np.random.default_rng(seed)
     fx, fy, cx, cy = K_REF
     # camera centres on the upper hemisphere (golden-angle spiral, deterministic)
@@ -56,6 +75,8 @@ def make_scene(n_cams, n_pts, obs_per_point=None, seed=0, noise_px=0.5,
     phi = i * np.pi * (3.0 - np.sqrt(5.0))
     rad = np.sqrt(1.0 - zc * zc)
     centres = radius * np.stack([rad * np.cos(phi), rad * np.sin(phi), zc], axis=1)
+    if visibility == "nearest":
+        centres = centres[coherent_camera_order(centres)]
     cams = np.zeros((n_cams, 10))
     for c in range(n_cams):
         zax = -centres[c] / np.linalg.norm(centres[c])
@@ -68,8 +89,19 @@ def make_scene(n_cams, n_pts, obs_per_point=None, seed=0, noise_px=0.5,
         cams[c, 6:] = (fx, fy, cx, cy)
     pts = rng.uniform(-1.0, 1.0, size=(n_pts, 3))
     L = n_cams if obs_per_point is None else int(obs_per_point)
+    if visibility == "nearest":
+        # surface points of the upper unit sphere (what an object in front of the cameras shows them)
+        v = rng.normal(size=(n_pts, 3)); v[:, 2] = np.abs(v[:, 2]) * 0.8 + 0.15
+        pts = v / np.linalg.norm(v, axis=1, keepdims=True)
     if L >= n_cams:
         cam_idx = np.tile(np.arange(n_cams, dtype=np.int64), n_pts)
+    elif visibility == "nearest":
+        cdir = centres / np.linalg.norm(centres, axis=1, keepdims=True)
+        cam_idx = np.empty((n_pts, L), dtype=np.int64)
+        for a in range(0, n_pts, 65536):                       # chunks keep the [points, cameras] score matrix small
+            score = pts[a:a + 65536] @ cdir.T
+            cam_idx[a:a + 65536] = np.sort(np.argpartition(-score, L, axis=1)[:, :L], axis=1)
+        cam_idx = cam_idx.ravel()
     else:
         # L distinct cameras per point, ascending camera id inside a track
         keys = rng.random((n_pts, n_cams))

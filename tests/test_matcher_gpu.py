@@ -300,8 +300,26 @@ def test_batched_pairs_vs_oracle_and_degenerate_sizes(gpu_ready):
     for (i, j), (q, t, d) in zip([(0, 1), (1, 3), (3, 0)], got):
         rq, rt, rd = mo.match_features(sets[i], sets[j], 0.75, "l2")
         assert np.array_equal(q, rq) and np.array_equal(t, rt) and np.array_equal(d, rd)
-    with pytest.raises(ValueError, match="not enough values to unpack"):      # train image with ONE descriptor (find_matches.py:151)
-        match_pairs(sets, [(0, 1), (0, 2)])
+    # train image with ONE descriptor (find_matches.py:151): THAT pair carries the ValueError, the others their matches -
+    # the reference's per-pair try / except (:344-350) skips only the failing pair
+    got2 = match_pairs(sets, [(0, 1), (0, 2), (1, 3)])
+    assert isinstance(got2[1], ValueError) and "not enough values to unpack" in str(got2[1])
+    assert all(np.array_equal(a, b) for a, b in zip(got2[0], got[0])) and all(np.array_equal(a, b) for a, b in zip(got2[2], got[1]))
+    from sfm_amd.matcher import ImageMatcher
+    ms = ImageMatcher().match_features_batched(sets, [(0, 1), (0, 2)])
+    assert ms[1] is None and len(ms[0]) == len(got[0][0])
+    # an image without keypoints (cv2 returns None) is an empty set; an image no pair refers to may be anything
+    got3 = match_pairs([sets[0], None, sets[1], np.zeros((5, 7), np.float32)], [(0, 1), (1, 0), (0, 2)])
+    assert len(got3[0][0]) == 0 and len(got3[1][0]) == 0 and all(np.array_equal(a, b) for a, b in zip(got3[2], got[0]))
+    # one image with non-integral floats: only the pairs touching it leave the exact uint8 path, every pair still equals
+    # its own match_arrays call bit for bit
+    from sfm_amd.matcher import match_arrays
+    frac = sets[3].astype(np.float32) + np.float32(0.25)
+    mixed = [sets[0], sets[1], frac]
+    prs = [(0, 1), (1, 2), (2, 0), (1, 0)]
+    for (i, j), (q, t, d) in zip(prs, match_pairs(mixed, prs)):
+        rq, rt, rd = match_arrays(mixed[i], mixed[j])
+        assert np.array_equal(q, rq) and np.array_equal(t, rt) and np.array_equal(d, rd), (i, j)
     far_q, far_t = far_apart_sets(40, 600, 128, seed=3)                        # re-rank path inside a batch
     ordinary = _image_sets([300], seed=2)[0].astype(np.uint8)
     got = match_pairs([far_q, far_t, ordinary], [(2, 2), (0, 1), (2, 1)], ratio=2.0)     # ratio 2: every query row is kept

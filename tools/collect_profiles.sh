@@ -6,8 +6,12 @@
 set -u
 ROUND=${1:-r02}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
-OUT=$R/gpurun_out/prof_$ROUND
-rm -rf "$OUT"; mkdir -p "$OUT"
+# every collection gets a directory of its own (gpurun MERGES gpurun_out/ back, it does not replace it: a fixed directory
+# would accumulate one file set per collection and the summariser could pick a stale one - round 2 did)
+STAMP=$(date -u +%Y%m%dT%H%M%SZ)
+OUT=$R/gpurun_out/prof_$ROUND/$STAMP
+mkdir -p "$OUT"
+(cd $R && git rev-parse HEAD 2>/dev/null; sha256sum sfm_amd/lib/libsfm_amd.so bench.py) > $OUT/provenance.txt 2>&1
 cd /tmp && export TMPDIR=/tmp
 BA="--no-cpu-baseline --no-matcher --no-d6 --no-mixed --no-pcg --no-dropin --no-driver-rows --no-alt-camera-solver"
 echo "[1/7] bench line (defaults)";           python3 $R/bench.py > $OUT/bench.json 2> $OUT/bench.err || exit 1
@@ -28,4 +32,5 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt5 -- python3 $R/b
 # keep only what the summariser reads (the raw traces are large)
 find $OUT -name "*kernel_trace.csv" -size +20M -delete
 du -sh $OUT
+date -u +%Y%m%dT%H%M%SZ > $OUT/done
 echo done

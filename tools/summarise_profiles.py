@@ -10,8 +10,15 @@ import collections, csv, glob, json, os, shutil, sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 rnd = sys.argv[1] if len(sys.argv) > 1 else "r02"
-src = os.path.join(ROOT, "gpurun_out", "prof_" + rnd)
+# tools/collect_profiles.sh writes every collection into a time-stamped directory of its own and drops a `done` marker
+# last: take the NEWEST complete one (gpurun merges gpurun_out/ back, so older collections stay next to it)
+base = os.path.join(ROOT, "gpurun_out", "prof_" + rnd)
+runs = sorted(d for d in glob.glob(os.path.join(base, "*")) if os.path.isdir(d) and os.path.exists(os.path.join(d, "done")))
+if not runs:
+    raise SystemExit(f"no complete collection under {base} (tools/collect_profiles.sh {rnd})")
+src = runs[-1]
 dst = os.path.join(ROOT, "profiles")
+print("summarising", src)
 
 
 def short(name):
@@ -29,6 +36,8 @@ def counters(d, wanted=None):
 
 def copy_stats(sub, out_name):
     fs = glob.glob(os.path.join(src, sub, "**", "*kernel_stats.csv"), recursive=True)
+    if len(fs) > 1:
+        raise SystemExit(f"{len(fs)} kernel_stats files under {src}/{sub}: one collection must hold one")
     if fs:
         shutil.copy(fs[0], os.path.join(dst, out_name))
         return fs[0]
