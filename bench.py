@@ -50,6 +50,10 @@ def parse():
                     help="how the formed camera system is solved in the headline run")
     ap.add_argument("--no-alt-camera-solver", action="store_true")
     ap.add_argument("--no-driver-rows", action="store_true")
+    ap.add_argument("--visibility", default="random", choices=("random", "nearest"),
+                    help="random: the BASELINE scene (L cameras per track drawn uniformly); nearest: spatially coherent scene "
+                         "(each point seen by its L nearest cameras, cameras numbered along the hemisphere)")
+    ap.add_argument("--no-coherent", action="store_true", help="skip the secondary row on the spatially coherent scene")
     return ap.parse_args()
 
 
@@ -83,11 +87,57 @@ def main():
         # stdout carries ONE JSON line: keep RCCL's version banner (printed to stdout at NCCL_DEBUG=VERSION) out of it
         if os.environ.get("NCCL_DEBUG", "").upper() == "VERSION":
             os.environ["NCCL_DEBUG"] = "WARN"
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-        comm = DistComm()
+        # stdout carries ONE JSON line, but RCCL writes its warnings and version banner there while communicators come up
+        # (torch creates its own lazily, at the first collective): file descriptor 1 points at stderr until both exist
+        sys.stdout.flush()
+        saved_fd = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+            # the exchanges run inside the library (sfm_comm_*: ncclAllReduce on the handle's stream, no host round trip per
+            # exchange); torch.distributed only ships the 128-byte RCCL id and takes the timing barrier.  Checked against
+            # torch.distributed's own all-reduce before use; SFM_BENCH_COMM=torch keeps the Python-callback route.
+            comm, comm_kind = None, "torch.distributed all_reduce from Python callbacks (DistComm)"
+            if os.environ.get("SFM_BENCH_COMM", "rccl") != "torch":
+                # every rank runs the same two torch collectives whatever happens locally, so a local failure cannot
+                # leave the other ranks waiting in a collective
+                rc_, local_ok = None, 1.0
+                try:
+                    from sfm_amd.comm import RcclComm
+                    rc_ = RcclComm(device=local_rank)
+                except Exception as e:
+                    local_ok = 0.0
+                    print("bench: in-library RCCL unavailable (%r); using torch.distributed callbacks" % (e,), file=sys.stderr)
+                probe = torch.arange(1, 1025, dtype=torch.float64, device="cuda") * (rank + 1)
+                want = probe.clone()
+                dist.all_reduce(want)
+                if rc_ is not None:
+                    try:
+                        rc_.allreduce_sum(probe)
+                        torch.cuda.synchronize()
+                        local_ok = 1.0 if torch.equal(probe, want) else 0.0
+                    except Exception as e:
+                        local_ok = 0.0
+                        print("bench: in-library all-reduce failed (%r)" % (e,), file=sys.stderr)
+                ok = torch.tensor([local_ok], dtype=torch.float64, device="cuda")
+                dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+                if float(ok.item()) == 1.0:
+                    comm, comm_kind = rc_, "RCCL inside libsfm_amd.so (sfm_comm_reduce_hook: ncclAllReduce on the handle's stream)"
+                elif rc_ is not None:
+                    rc_.close()
+            if comm is None:
+                warm_t = torch.ones(8, dtype=torch.float64, device="cuda")
+                dist.all_reduce(warm_t)
+            torch.cuda.synchronize()
+        finally:
+            sys.stdout.flush()
+            os.dup2(saved_fd, 1)
+            os.close(saved_fd)
+        if comm is None:
+            comm = DistComm()
         comm.force = True
     else:
-        comm = LocalComm()
+        comm, comm_kind = LocalComm(), "single rank"
 
     def barrier_sync():
         torch.cuda.synchronize()
@@ -104,7 +154,8 @@ def main():
 
     # ------------------------------------------------------------------ BA workload (cfg4 by default)
     C, P, Lobs, d = args.cams, args.pts, args.obs_per_point, args.cam_dim
-    sc = synth.make_scene(C, P, obs_per_point=Lobs, seed=1004, noise_px=0.5, pt_sigma=0.02, cam_sigma=0.002)
+    sc = synth.make_scene(C, P, obs_per_point=Lobs, seed=1004, noise_px=0.5, pt_sigma=0.02, cam_sigma=0.002,
+                          visibility=args.visibility)
     lo, hi = (0, P)
     if world > 1:
         pt_ptr = np.zeros(P + 1, dtype=np.int64)
@@ -114,9 +165,20 @@ def main():
     n_obs_total = sc.n_obs
     n_sys = C * d
 
-    def fixed_schedule_run(cam_dim, precision, profile, solver="dense", camera_solver=None):
+    def shard_scene(scene):
+        """This rank's shard of a scene: (cams0, pts0, cam_idx, pt_idx, uv)."""
+        a, b = 0, P
+        if world > 1:
+            pp = np.zeros(P + 1, dtype=np.int64)
+            np.cumsum(np.bincount(scene.pt_idx, minlength=P), out=pp[1:])
+            a, b = partition_points(pp, world)[rank]
+        ci_, pi_, uv_, pts_ = shard_arrays(scene.cam_idx, scene.pt_idx, scene.uv, scene.pts0, a, b)
+        return scene.cams0, pts_, ci_, pi_, uv_
+
+    def fixed_schedule_run(cam_dim, precision, profile, solver="dense", camera_solver=None, shard=None):
         """W warm-up + K timed outer iterations of the trust-region loop (library side, termination tests off)."""
-        be = GpuBA(sc.cams0[:, :cam_dim], pts0, ci, pi, uv, synth.K_REF, device=local_rank, comm=comm, precision=precision,
+        cams0_, pts0_, ci_, pi_, uv_ = shard if shard is not None else (sc.cams0, pts0, ci, pi, uv)
+        be = GpuBA(cams0_[:, :cam_dim], pts0_, ci_, pi_, uv_, synth.K_REF, device=local_rank, comm=comm, precision=precision,
                    solver=solver, camera_solver=camera_solver or args.camera_solver)
         st = be.trf_begin(max_nfev=2 ** 31 - 1, check_tolerances=False)
         cost0 = st.result().cost
@@ -268,6 +330,32 @@ def main():
                            "(sfm_ba_solve_pcg: S never formed; rtol 1e-13): the multi-rank / many-camera route")
         ba_pcg["cg_iterations_total_incl_warmup"] = rp["cg_iters"]
         ba_pcg["kernels_us"] = {k: round(v[0] / v[1] * 1e3, 2) for k, v in rp["prof"].items() if v[1] > 0}
+
+    # ---- the same sizes on a spatially coherent scene (what a real capture is: the reference's shipped bunny set has 36 views
+    # around the object and tracks between neighbouring views only): each point seen by its L nearest cameras, cameras
+    # numbered along the hemisphere.  Secondary row: the headline stays the uniformly random BASELINE scene.
+    ba_coherent = None
+    if args.visibility == "random" and not args.no_coherent:
+        sc2 = synth.make_scene(C, P, obs_per_point=Lobs, seed=1004, noise_px=0.5, pt_sigma=0.02, cam_sigma=0.002, visibility="nearest")
+        rc2 = fixed_schedule_run(d, "fp64", True, shard=shard_scene(sc2))
+        ba_coherent = brief(rc2, "same sizes, spatially coherent visibility (synth.make_scene(visibility='nearest')): each point seen by "
+                                 "its L nearest cameras, cameras numbered along the hemisphere")
+        ba_coherent["kernels_us"] = {k: round(v[0] / v[1] * 1e3, 2) for k, v in rc2["prof"].items() if v[1] > 0}
+        ba_coherent["n_pairs"] = rc2["n_pairs"]
+        uq = rc2["n_obs_local"] * 3 * d * 8 + rc2["n_pairs"] * 8.0
+        si = ba_coherent["kernels_us"].get("schur_items")
+        if si:
+            ba_coherent["k_schur_items"] = {"avg_us": si, "unique_bytes": uq, "frac": round(uq / (si * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)}
+            for name in ("r03_pmc_summary_coherent.json",):
+                try:
+                    pmc = json.load(open(os.path.join(ROOT, "profiles", name)))
+                    wl = pmc["workload"]
+                    if world == 1 and (wl["cams"], wl["pts"], wl["obs"], wl["cam_dim"]) == (C, P, sc2.n_obs, d):
+                        t = pmc["k_schur_items"]["hbm_bytes_per_launch"]
+                        ba_coherent["k_schur_items"].update(traffic=t, wasted_traffic=round(t / uq, 2), traffic_source="profiles/" + name)
+                except (OSError, KeyError, ValueError):
+                    pass
+        del sc2
 
     # ------------------------------------------------------------------ end-to-end drop-in call (N = 1 only)
     # wall clock of ONE StructureFromMotion.bundle_adjust() with the reference's settings (ftol = xtol = 1e-4,
@@ -424,8 +512,10 @@ def main():
             "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"BA: {C} cams / {P} pts / {n_obs_total} obs, cam block {d} "
                                    f"({'reference 10-parameter block + regulariser' if d == 10 else 'fixed K'}), "
-                                   "aligned residual order, Huber, SciPy-TRF control flow, fixed schedule",
+                                   "aligned residual order, Huber, SciPy-TRF control flow, fixed schedule"
+                                   + ("" if args.visibility == "random" else ", spatially coherent visibility"),
                        "parallelism": f"points sharded over {world} rank(s), cameras replicated, RCCL all-reduce of [S|r]",
+                       "comm": comm_kind,
                        "seed": 1004},
             "ba": {"damped_solves": main["damped_solves"], "trial_steps": main["trial_steps"], "cost_start": main["cost_start"],
                    "cost_end": main["cost_end"], "solves_per_s": main["damped_solves"] / elapsed, "kernels": kernels,
@@ -433,6 +523,7 @@ def main():
                    "loop": "sfm_ba_trf_outer (library-side trust-region loop)", "camera_solver": args.camera_solver,
                    "camera_cg_iterations_and_fallbacks_incl_warmup": main["camera_cg"]},
             "ba_cam_dim6": ba_d6, "ba_mixed_precision": ba_mixed, "ba_other_camera_solver": ba_alt, "ba_pcg_solver": ba_pcg,
+            "ba_coherent_scene": ba_coherent,
             "dropin": dropin,
             "roofline": roofline, "rooflines": roofs, "cpu_baseline": cpu_baseline, "matcher": matcher,
             "driver_rows": driver_rows,

@@ -150,6 +150,23 @@ typedef struct sfm_ba_prob* sfm_ba_problem;    /* opaque; owns its index structu
  * NULL = single rank. */
 typedef int (*sfm_reduce_fn)(void* user, void* data, int64_t count, int op);
 
+/* ---- collectives inside the library (multi-rank: points sharded over GPUs, cameras replicated - SURVEY.md section 8e).
+ * RCCL (= NCCL's API over xGMI) is dlopen'ed on first use, so nothing here is needed on one GPU.  One communicator per
+ * handle; sfm_comm_allreduce enqueues ncclAllReduce (float64, in place, op 0 = SUM / 1 = MAX) on the handle's stream: no
+ * host synchronisation.  sfm_comm_reduce_hook IS an sfm_reduce_fn: pass it as `reduce` with the handle as `reduce_user`
+ * and every exchange of the trust-region loop / of sfm_ba_solve_pcg runs on the stream between the stages.
+ * Bootstrap like any NCCL program: rank 0 calls sfm_comm_unique_id and ships the 128 bytes to the other ranks by whatever
+ * the host has (MPI, a file, torch.distributed), then every rank calls sfm_comm_init_rank (collective).  A host that
+ * already owns an ncclComm_t for the handle's device hands it over with sfm_comm_adopt (not destroyed by the library). */
+enum { SFM_COMM_ID_BYTES = 128 };
+int sfm_comm_unique_id(sfm_handle h, void* id_host);
+int sfm_comm_init_rank(sfm_handle h, const void* id_host, int32_t n_ranks, int32_t rank);
+int sfm_comm_adopt(sfm_handle h, void* nccl_comm, int32_t n_ranks, int32_t rank);
+int sfm_comm_destroy(sfm_handle h);
+int sfm_comm_info(sfm_handle h, int32_t* n_ranks_host, int32_t* rank_host);      /* 0 ranks: no communicator */
+int sfm_comm_allreduce(sfm_handle h, double* data, int64_t count, int op);
+int sfm_comm_reduce_hook(void* handle_as_user, void* data, int64_t count, int op);
+
 /* Validates the indices and builds, ON THE DEVICE, everything the kernels need besides the arrays above:
  * per-point / per-camera observation lists, the camera-pair lists of the Schur complement and their split
  * into work items (sfm_ba_structure shows them).  Synchronises the stream (sizes are data-dependent).
@@ -195,7 +212,8 @@ typedef struct {
   int64_t reduce_step_off, reduce_step_count;   /* doubles: [||J~ s||^2 | f~^T J~ s | cost(x+s) | ||s_pts||^2 | ||x_pts+s_pts||^2 ] SUM */
   int64_t pc_off, pp_off;           /* camera / point part of p = -(H + alpha I)^-1 g */
   int64_t scalars_off;              /* 16 doubles, see SFM_SC_* */
-  int64_t G_off;                    /* [n_obs][3][cam_dim] */
+  int64_t G_off;                    /* [n_obs][G stride]: [3][cam_dim] doubles per observation, padded to 32 doubles (256 B = two whole
+                                       128-byte lines) for cam_dim 10, 18 for cam_dim 6 */
   int64_t cg_Ap_off, cg_M_off;      /* sfm_ba_solve_pcg: S p [n] and the block-Jacobi blocks [n_cams][cam_dim][cam_dim] (this rank's partial sums) SUM */
 } sfm_ba_layout;
 

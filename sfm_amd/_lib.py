@@ -78,6 +78,13 @@ SIGNATURES = {
     "sfm_match_knn2_batched": (C.c_int, [vp, C.c_int, vp, i64, vp, i64, C.c_int, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i64]),
     "sfm_match_ratio_batched": (C.c_int, [vp, i64, i32, vp, vp, vp, vp, f64, vp, vp, vp, vp, vp, i64]),
     "sfm_copy_to_host": (C.c_int, [vp, vp, vp, i64]),
+    "sfm_comm_unique_id": (C.c_int, [vp, vp]),
+    "sfm_comm_init_rank": (C.c_int, [vp, vp, i32, i32]),
+    "sfm_comm_adopt": (C.c_int, [vp, vp, i32, i32]),
+    "sfm_comm_destroy": (C.c_int, [vp]),
+    "sfm_comm_info": (C.c_int, [vp, C.POINTER(i32), C.POINTER(i32)]),
+    "sfm_comm_allreduce": (C.c_int, [vp, vp, i64, C.c_int]),
+    "sfm_comm_reduce_hook": (C.c_int, [vp, vp, i64, C.c_int]),
     "sfm_ba_create_problem": (C.c_int, [vp, C.POINTER(BADesc), C.POINTER(vp)]),
     "sfm_ba_destroy_problem": (None, [vp]),
     "sfm_ba_get_structure": (C.c_int, [vp, C.POINTER(BAStructureView)]),

@@ -176,10 +176,10 @@ class GpuBA:
         L = self.lay
         wq = 1 if want_q else 0
         if self.solver == "pcg":
-            fn, _keep = self._reduce_hook()
+            fn, _keep, user = self._reduce_hook()
             its = C.c_int32(0)
             self.h.call("sfm_ba_solve_pcg", self._pp, C.c_double(alpha), wq, C.c_double(self.pcg_rtol),
-                        self._pcg_max_iter(), fn, None, C.byref(its))
+                        self._pcg_max_iter(), fn, user, C.byref(its))
             self.cg_iters += its.value
             return self._solve_scalars(alpha)
         self.h.call("sfm_ba_schur_build", self._pp, C.c_double(alpha))
@@ -223,7 +223,10 @@ class GpuBA:
     def _reduce_hook(self):
         """ctypes callback the C loop calls between stages when the problem is sharded over ranks."""
         if not self._dist:
-            return _lib.REDUCE_FN(), None
+            return _lib.REDUCE_FN(), None, None
+        if getattr(self.comm, "in_library", False):       # RCCL inside the library: no Python between the stages
+            fn, user = self.comm.reduce_hook()
+            return fn, fn, user
         base = self.ws.data_ptr()
 
         def cb(_user, ptr, count, op):
@@ -237,7 +240,7 @@ class GpuBA:
                 return 1
 
         fn = _lib.REDUCE_FN(cb)
-        return fn, fn
+        return fn, fn, None
 
     def trf_begin(self, ftol=1e-4, xtol=1e-4, gtol=1e-8, max_nfev=100, max_outer=None, check_tolerances=True):
         return CTrf(self, ftol, xtol, gtol, max_nfev, max_outer, check_tolerances)
@@ -288,9 +291,9 @@ class CTrf:
         o.check_tolerances = 1 if check_tolerances else 0
         o.solver = _lib.SOLVER_PCG if be.solver == "pcg" else _lib.SOLVER_DENSE
         o.pcg_rtol, o.pcg_max_iter = be.pcg_rtol, be._pcg_max_iter()
-        self._fn, self._keep = be._reduce_hook()
+        self._fn, self._keep, user = be._reduce_hook()
         self._st = _lib.vp()
-        be.h.call("sfm_ba_trf_begin", be._pp, C.c_void_p(be.x.data_ptr()), C.byref(o), self._fn, None, C.byref(self._st))
+        be.h.call("sfm_ba_trf_begin", be._pp, C.c_void_p(be.x.data_ptr()), C.byref(o), self._fn, user, C.byref(self._st))
 
     def outer(self):
         more = C.c_int(0)

@@ -7,7 +7,7 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
-SRC = [os.path.join(HERE, "csrc", f) for f in ("ctx.hip", "ba.hip", "problem.hip", "trf.hip", "dense.hip", "match.hip", "driver.hip")]
+SRC = [os.path.join(HERE, "csrc", f) for f in ("ctx.hip", "ba.hip", "problem.hip", "trf.hip", "dense.hip", "match.hip", "driver.hip", "comm_rccl.hip")]
 import glob
 # every header under csrc/ (match_plan.h and trf_loop.h were missing from a hand-kept list once: a stale library then
 # ran under the GPU tests while the CPU sanitizer tests compiled the new header)
@@ -57,7 +57,7 @@ def build(force=False, verbose=True):
 
     with ThreadPoolExecutor(max_workers=min(len(SRC), os.cpu_count() or 1)) as ex:
         objs = list(ex.map(compile_one, SRC))
-    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs + ["-ldl"]
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.run(cmd, check=True)

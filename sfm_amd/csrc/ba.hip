@@ -29,6 +29,13 @@ typedef double v4d __attribute__((ext_vector_type(4)));
 #define SQRT_EPS_D 1.4901161193847656e-08
 #define CAMPRE 16   // r[3] t[3] fx fy cx cy  a b a1 b1 (Rodrigues coefficients)  |r|^2 pad
 
+// Stride of a G block in doubles.  D = 10: 32 = 256 bytes, so that a block is exactly two whole 128-byte lines - the Schur
+// gather is bound by the lines it pulls through the fabric, and a 240-byte block at 16-byte alignment straddles 2.75 on
+// average: k_schur_items 357 -> 305 us, fabric traffic 2.34 -> 1.94 GB per launch (round 3, profiles/).  SFM_G_PAD=0 restores
+// the packed 30.  D = 6: 18 doubles = 144 bytes straddle exactly two lines at any 16-byte offset already.
+static int g_pad() { static const int v = (getenv("SFM_G_PAD") && getenv("SFM_G_PAD")[0] == '0') ? 0 : 1; return v; }
+static int64_t g_stride(int64_t D) { return (D == 10 && g_pad()) ? 32 : 3 * D; }
+
 // ------------------------------------------------------------------------------------ layout
 Lay ba_layout(int64_t C, int64_t P, int64_t N, int64_t D, int64_t n_items, int64_t n_cchunks, int precision) {
   Lay L;
@@ -51,7 +58,7 @@ Lay ba_layout(int64_t C, int64_t P, int64_t N, int64_t D, int64_t n_items, int64
   L.e = take(P * 3);
   L.v = take(P * 3);
   L.tmp3 = take(N * 3);
-  L.G = take(N * 3 * D);                           // always float64 (see the header of this file)
+  L.G = take(N * g_stride(D));                     // always float64 (see the header of this file)
   L.eobs = take(N * 3);                 // e_j = M g_pj copied per observation (read with the G row by the diagonal Schur items)
   L.red_lin = take(2 * n + 2);
   L.gmax = take(2);
@@ -511,34 +518,96 @@ __global__ void k_point_factor(int P, double alpha, const double* __restrict__ C
   e[(size_t)j * 3 + 2] = m20 * g0 + m21 * g1 + m22 * g2;
 }
 
-// G_k[m][a] = sum_r Jc~[r][a] * V[r][m],  V = Jp~ M^T (2x3).  16 lanes per observation (a = lane & 15 < D),
-// each lane produces the three m entries of its column: Jc~ reads and G writes are contiguous over a, the
-// 12 doubles of Jp~ and M are the same address for the whole group (one request per group).
+// G_k[m][a] = sum_r Jc~[r][a] * V[r][m],  V = Jp~ M^T (2x3); e_j copied next to the observation (k_schur_items, diagonal
+// items).  One thread per observation, 256 observations per workgroup, and - as in k_lin_obs - both directions pass through
+// LDS so that HBM only sees contiguous streams: the Jacobian rows of the 256 observations come in as one flat coalesced
+// read, every thread picks its 2 D + 6 values out of LDS (odd row stride: no bank conflicts), gathers its point's M (six
+// doubles; the ten observations of a track share them) and leaves its GS outputs in the same LDS buffer, which then goes
+// out as 16-byte stores, 64 KB contiguous per workgroup (GS = 32: the padding doubles are written as zeros).
+// Round 2's form (16 lanes per observation, three 8-byte stores per lane 80 bytes apart) moved the same bytes at 3.3 TB/s.
 template <int D, typename T, typename TG, int GS>
 __global__ __launch_bounds__(256) void k_build_G(int64_t N, const int* __restrict__ pt_idx,
                                                  const T* __restrict__ recA, const T* __restrict__ recB,
                                                  const double* __restrict__ Linv, TG* __restrict__ G,
                                                  const double* __restrict__ e, double* __restrict__ eobs) {
-  const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  const int64_t k = t >> 4;
-  const int a = (int)(t & 15);
-  if (k >= N || a >= D + 3) return;
-  // lanes a < D: one column of G each.  Lanes D .. D+2 copy e_j next to the observation (k_schur_items, diagonal items):
-  // the same loads with other addresses, so that the wave does not run two dependent-load chains one after the other
-  const bool col = a < D;
-  const int64_t pj = pt_idx[k];
-  const T* r = recA + (size_t)k * (2 * D);
+  static_assert(GS % 2 == 0 && GS >= 3 * D, "G blocks are written as 16-byte pieces");
+  constexpr int WA = 2 * D, LDA = WA + 1, LDB = 9, LDG = GS + 1;
+  constexpr int VE = 16 / (int)sizeof(T);                // elements per 16-byte load
+  constexpr int NA = WA / VE, NB = 8 / VE;               // 16-byte loads per thread for the two record arrays of 256 observations
+  static_assert(WA % VE == 0 && 8 % VE == 0, "record rows are whole 16-byte pieces");
+  constexpr int IN_DOUBLES = 256 * (LDA + LDB), OUT_DOUBLES = 256 * LDG;
+  __shared__ double s_buf[IN_DOUBLES > OUT_DOUBLES ? IN_DOUBLES : OUT_DOUBLES];
+  double* s_jp = s_buf + 256 * LDA;                       // recB records, stride 9
+  typedef T vec_t __attribute__((ext_vector_type(VE)));
+  const int tid = threadIdx.x;
+  const int64_t k0 = (int64_t)blockIdx.x * 256;
+  const int nvalid = (int)((N - k0) < 256 ? (N - k0) : 256);
+  const bool live = tid < nvalid;
+  // every global load of the workgroup is issued before anything waits: the point id first (the M / e gathers depend on it),
+  // then the flat, coalesced 16-byte pieces of the two record arrays, then the gathers
+  const int64_t k = k0 + tid;
+  const int64_t pj = live ? pt_idx[k] : 0;
+  vec_t la[NA], lb[NB];
+  {
+    const vec_t* inA = (const vec_t*)(recA + (size_t)k0 * WA);
+    const vec_t* inB = (const vec_t*)(recB + (size_t)k0 * 8);
+#pragma unroll
+    for (int j = 0; j < NA; ++j) { const int i = tid + 256 * j; la[j] = i * VE < nvalid * WA ? inA[i] : (vec_t)(T)0; }
+#pragma unroll
+    for (int j = 0; j < NB; ++j) { const int i = tid + 256 * j; lb[j] = i * VE < nvalid * 8 ? inB[i] : (vec_t)(T)0; }
+  }
   const double* M = Linv + (size_t)pj * 6;
-  const T* jp = recB + (size_t)k * 8;
-  const double j0 = jp[0], j1 = jp[1], j2 = jp[2], j3 = jp[3], j4 = jp[4], j5 = jp[5];
   const double m00 = M[0], m10 = M[1], m11 = M[2], m20 = M[3], m21 = M[4], m22 = M[5];
-  const double c0 = col ? (double)r[a] : e[pj * 3 + (a - D)], c1 = col ? (double)r[D + a] : 0.0;
-  if (!col) { eobs[k * 3 + (a - D)] = c0; return; }
-  TG* g = G + (size_t)k * GS + a;
-  g[0] = (TG)(c0 * (j0 * m00) + c1 * (j3 * m00));
-  g[D] = (TG)(c0 * (j0 * m10 + j1 * m11) + c1 * (j3 * m10 + j4 * m11));
-  g[2 * D] = (TG)(c0 * (j0 * m20 + j1 * m21 + j2 * m22) + c1 * (j3 * m20 + j4 * m21 + j5 * m22));
-  if (GS > 3 * D && a < GS - 3 * D) g[3 * D] = (TG)0;     // padding of the block (read as part of a 16-byte chunk, never used)
+  const double e0 = e[pj * 3], e1 = e[pj * 3 + 1], e2 = e[pj * 3 + 2];
+#pragma unroll
+  for (int j = 0; j < NA; ++j)
+#pragma unroll
+    for (int v = 0; v < VE; ++v) { const int i = (tid + 256 * j) * VE + v, t = i / WA, q = i - t * WA; s_buf[t * LDA + q] = (double)la[j][v]; }
+#pragma unroll
+  for (int j = 0; j < NB; ++j)
+#pragma unroll
+    for (int v = 0; v < VE; ++v) { const int i = (tid + 256 * j) * VE + v; s_jp[(i >> 3) * LDB + (i & 7)] = (double)lb[j][v]; }
+  __syncthreads();
+  double g[3 * D];
+  {
+    const double* jp = &s_jp[tid * LDB];
+    const double j0 = jp[0], j1 = jp[1], j2 = jp[2], j3 = jp[3], j4 = jp[4], j5 = jp[5];
+    // V[r][m] = sum_q Jp~[r][q] M[m][q]  (M lower triangular)
+    const double v00 = j0 * m00, v01 = j0 * m10 + j1 * m11, v02 = j0 * m20 + j1 * m21 + j2 * m22;
+    const double v10 = j3 * m00, v11 = j3 * m10 + j4 * m11, v12 = j3 * m20 + j4 * m21 + j5 * m22;
+    const double* my = &s_buf[tid * LDA];
+#pragma unroll
+    for (int a = 0; a < D; ++a) {
+      const double c0 = my[a], c1 = my[D + a];
+      g[a] = c0 * v00 + c1 * v10;
+      g[D + a] = c0 * v01 + c1 * v11;
+      g[2 * D + a] = c0 * v02 + c1 * v12;
+    }
+  }
+  if (live) { eobs[k * 3] = e0; eobs[k * 3 + 1] = e1; eobs[k * 3 + 2] = e2; }
+  __syncthreads();                                      // everybody has its inputs in registers: the buffer becomes the output stage
+  {
+    double* my = &s_buf[tid * LDG];
+#pragma unroll
+    for (int q = 0; q < 3 * D; ++q) my[q] = g[q];
+#pragma unroll
+    for (int q = 3 * D; q < GS; ++q) my[q] = 0.0;       // padding of the block (read as part of a 16-byte chunk, never used)
+  }
+  __syncthreads();
+  {
+    typedef TG pair_t __attribute__((ext_vector_type(2)));
+    pair_t* outp = (pair_t*)(G + (size_t)k0 * GS);
+    constexpr int HP = GS / 2;
+#pragma unroll
+    for (int j = 0; j < HP; ++j) {
+      const int i = tid + 256 * j;
+      if (i < nvalid * HP) {
+        const int t = i / HP, q = 2 * (i - t * HP);
+        pair_t v; v.x = (TG)s_buf[t * LDG + q]; v.y = (TG)s_buf[t * LDG + q + 1];
+        outp[i] = v;
+      }
+    }
+  }
 }
 
 // Reduced camera system  S[c][c2] = [c == c2] B_c - sum_{(k,k2) on a shared track} G_k G_k2^T  (c <= c2, mirrored).
@@ -1024,11 +1093,15 @@ static int check_problem(sfm_ctx* h, sfm_ba_problem p, Lay* L) {
 #define DISPATCH_DT(D, PREC, ...)                                                                     \
   do {                                                                                                \
     if ((PREC) == SFM_BA_MIXED) {                                                                     \
-      if ((D) == 10) { constexpr int DD = 10; constexpr int GG = 30; typedef float TT; __VA_ARGS__; } \
-      else { constexpr int DD = 6; constexpr int GG = 18; typedef float TT; __VA_ARGS__; }            \
+      if ((D) == 10) {                                                                                \
+        if (g_pad()) { constexpr int DD = 10; constexpr int GG = 32; typedef float TT; __VA_ARGS__; } \
+        else { constexpr int DD = 10; constexpr int GG = 30; typedef float TT; __VA_ARGS__; }         \
+      } else { constexpr int DD = 6; constexpr int GG = 18; typedef float TT; __VA_ARGS__; }          \
     } else {                                                                                          \
-      if ((D) == 10) { constexpr int DD = 10; constexpr int GG = 30; typedef double TT; __VA_ARGS__; } \
-      else { constexpr int DD = 6; constexpr int GG = 18; typedef double TT; __VA_ARGS__; }           \
+      if ((D) == 10) {                                                                                \
+        if (g_pad()) { constexpr int DD = 10; constexpr int GG = 32; typedef double TT; __VA_ARGS__; } \
+        else { constexpr int DD = 10; constexpr int GG = 30; typedef double TT; __VA_ARGS__; }        \
+      } else { constexpr int DD = 6; constexpr int GG = 18; typedef double TT; __VA_ARGS__; }         \
     }                                                                                                 \
   } while (0)
 #define WST(L, field) ((TT*)(ws + (L).field))
@@ -1162,7 +1235,7 @@ extern "C" int sfm_ba_schur_build(sfm_handle h, sfm_ba_problem p, double alpha) 
   hipLaunchKernelGGL(k_point_factor, dim3(cdiv(P, 256)), dim3(256), 0, h->stream, P, alpha, WS(L, Cp), WS(L, gp),
                      WS(L, Linv), WS(L, e));
   DISPATCH_DT(D, p->precision, {
-    hipLaunchKernelGGL((k_build_G<DD, TT, double, GG>), dim3(cdiv(N * 16, 256)), dim3(256), 0, h->stream, N, p->pt_idx, WST(L, recA),
+    hipLaunchKernelGGL((k_build_G<DD, TT, double, GG>), dim3(cdiv(N, 256)), dim3(256), 0, h->stream, N, p->pt_idx, WST(L, recA),
                        WST(L, recB), WS(L, Linv), WS(L, G), WS(L, e), WS(L, eobs));
     sfm_prof_end(h, SFM_PROF_BUILD_G);
     sfm_prof_begin(h, SFM_PROF_SCHUR);
@@ -2097,7 +2170,7 @@ extern "C" int sfm_ba_solve_pcg(sfm_handle h, sfm_ba_problem p, double alpha, in
   sfm_prof_begin(h, SFM_PROF_BUILD_G);
   hipLaunchKernelGGL(k_point_factor, dim3(cdiv(P, 256)), dim3(256), 0, h->stream, P, alpha, WS(L, Cp), WS(L, gp), WS(L, Linv), WS(L, e));
   DISPATCH_DT(D, p->precision, {
-    hipLaunchKernelGGL((k_build_G<DD, TT, double, GG>), dim3(cdiv(N * 16, 256)), dim3(256), 0, h->stream, N, p->pt_idx, WST(L, recA),
+    hipLaunchKernelGGL((k_build_G<DD, TT, double, GG>), dim3(cdiv(N, 256)), dim3(256), 0, h->stream, N, p->pt_idx, WST(L, recA),
                        WST(L, recB), WS(L, Linv), WS(L, G), WS(L, e), WS(L, eobs));
     sfm_prof_end(h, SFM_PROF_BUILD_G);
     sfm_prof_begin(h, SFM_PROF_SCHUR);

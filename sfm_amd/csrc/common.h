@@ -23,6 +23,8 @@ struct sfm_ctx {
   sfm_prof_slot prof[SFM_PROF_COUNT];
   void* scratch;           // growable device scratch for calls that take no workspace (sfm_scratch)
   size_t scratch_bytes;
+  void* comm;              // ncclComm_t of this handle (comm_rccl.hip), or null
+  int comm_owned, comm_ranks, comm_rank;
   unsigned cgs_seq;        // k_cgs_persist: per-launch salt of the granule tags (24 bits, never 0)
   int cgs_persist_off;     // set once a persistent CG launch had to be abandoned: per-launch kernel from then on
 };

@@ -23,6 +23,7 @@ extern "C" int sfm_create(int device, sfm_handle* out) {
   h->profiling = 0;
   h->scratch = nullptr;
   h->scratch_bytes = 0;
+  h->comm = nullptr; h->comm_owned = 0; h->comm_ranks = 0; h->comm_rank = 0;
   h->cgs_seq = 0;
   h->cgs_persist_off = 0;
   memset(h->prof, 0, sizeof(h->prof));
@@ -85,6 +86,7 @@ extern "C" int sfm_profile_read(sfm_handle h, int slot, double* total_ms_host, i
 
 extern "C" void sfm_destroy(sfm_handle h) {
   if (!h) return;
+  (void)sfm_comm_destroy(h);
   if (h->prof[0].start[0])
     for (int k = 0; k < SFM_PROF_COUNT; ++k)
       for (int i = 0; i < SFM_PROF_RING; ++i) {

@@ -12,6 +12,7 @@
 // sfm_amd/structure.py is the host-side mirror (NumPy); tests/test_ba_gpu.py checks the arrays bit for bit.
 // The two global stable sorts and the prefix sums are rocPRIM device primitives (set-up plumbing, once per
 // problem); everything per-iteration is hand-written in ba.hip / dense.hip.
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 #include "ba_internal.h"
@@ -312,17 +313,35 @@ extern "C" int sfm_ba_create_problem(sfm_handle h, const sfm_ba_desc* d, sfm_ba_
   PB_HIP(hipMalloc((void**)&p->xcd_ptr, 9 * 4));
   hipLaunchKernelGGL(k_piece_fill, dim3(cdiv(n_blk, 256)), dim3(256), 0, st, n_blk, p->blk_ptr, p->item_ptr, ITEM_PAIRS,
                      p->item_beg, p->item_end);
-  // items grouped by block row mod 8, rows (and the items inside a row) in ascending order inside a group: C numbers, on the host
+  // items grouped by block row: 8 groups, one per XCD (workgroup b of the Schur kernel serves group b % 8); rows (and the
+  // items inside a row) stay in ascending order inside a group: C numbers, on the host.  Default: row r -> group r mod 8.
+  // SFM_XCD_GROUP=contig: contiguous row ranges balanced by item count - neighbouring block rows share their partner
+  // cameras when the camera numbering is spatially coherent (a capture order), so one XCD's L2 sees them together.
   {
+    const char* ge = getenv("SFM_XCD_GROUP");
+    const bool contig = ge && ge[0] == 'c';
+    std::vector<int> grp(C);
+    if (contig) {
+      long long total = 0, run = 0;
+      for (int r = 0; r < C; ++r) total += h_row_cnt[r];
+      for (int r = 0; r < C; ++r) {
+        const long long mid = run + h_row_cnt[r] / 2;                  // the group the middle of the row falls into
+        int g = total > 0 ? (int)((mid * 8) / total) : 0;
+        grp[r] = g > 7 ? 7 : g;
+        run += h_row_cnt[r];
+      }
+    } else {
+      for (int r = 0; r < C; ++r) grp[r] = r & 7;
+    }
     int xcd_ptr[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-    for (int r = 0; r < C; ++r) xcd_ptr[(r & 7) + 1] += h_row_cnt[r];
+    for (int r = 0; r < C; ++r) xcd_ptr[grp[r] + 1] += h_row_cnt[r];
     int64_t mx = 0;
     for (int g = 0; g < 8; ++g) { mx = xcd_ptr[g + 1] > mx ? xcd_ptr[g + 1] : mx; xcd_ptr[g + 1] += xcd_ptr[g]; }
     p->xcd_max_items = mx;
     std::vector<int> h_row_base(C);
     int run[8];
     for (int g = 0; g < 8; ++g) run[g] = xcd_ptr[g];
-    for (int r = 0; r < C; ++r) { h_row_base[r] = run[r & 7]; run[r & 7] += h_row_cnt[r]; }
+    for (int r = 0; r < C; ++r) { h_row_base[r] = run[grp[r]]; run[grp[r]] += h_row_cnt[r]; }
     PB_HIP(hipMemcpyAsync(p->xcd_ptr, xcd_ptr, 9 * 4, hipMemcpyHostToDevice, st));
     PB_HIP(hipMemcpyAsync(row_base, h_row_base.data(), (size_t)C * 4, hipMemcpyHostToDevice, st));
     hipLaunchKernelGGL(k_xcd_fill, dim3(4, C), dim3(256), 0, st, C, row_first, row_cnt, row_base, p->xcd_items);

@@ -98,6 +98,20 @@ class BundleAdjustMixin:
         a stalled solve or a non-finite step (SfmNumericError) is therefore logged and returned as False.
         What SciPy itself raises is raised here too (non-finite residuals at the start point: ValueError);
         a missing GPU / library still fails loudly (SfmError)."""
+        # The reconstruction state is ~1.3 M small containers at 100k points (track dicts, pixel lists, point lists).  Any
+        # full garbage collection that fires while this method allocates (the 200 pose tuples, the K matrices, 100k point
+        # lists) walks all of them: 50-100 ms each, several per call on an unlucky allocation count - the 3x spread of the
+        # write-back between otherwise identical boxes (round 2: 0.045 vs 0.154 s).  Nothing here creates cycles.
+        import gc
+        gc_was_on = gc.isenabled()
+        gc.disable()
+        try:
+            return self._bundle_adjust()
+        finally:
+            if gc_was_on:
+                gc.enable()
+
+    def _bundle_adjust(self):
         import time
         from ._lib import SfmNumericError
         from .ba import GpuBA
@@ -143,16 +157,7 @@ class BundleAdjustMixin:
             self.K = np.mean([np.array([[c[6], 0, c[8]], [0, c[7], c[9]], [0, 0, 1]]) for c in cams_new], axis=0)   # :532-538
         for idx, img_id in enumerate(ids):
             self.poses[img_id] = (rodrigues(cams_new[idx, :3]), cams_new[idx, 3:6].copy())
-        # 100k three-element lists: with the collector on, the allocation burst triggers full collections that walk the
-        # reconstruction's own containers over and over (measured 0.012 s without them, up to 0.16 s with)
-        import gc
-        gc_was_on = gc.isenabled()
-        gc.disable()
-        try:
-            self.points3D = pts_new.tolist()
-        finally:
-            if gc_was_on:
-                gc.enable()
+        self.points3D = pts_new.tolist()        # 100k three-element lists (0.012 s with the collector off, see bundle_adjust)
         self.last_ba_timing = {"pack_state": t_packed - t_start, "create_problem_and_upload": t_built - t_packed,
                                "solve": t_solved - t_built, "log_norms_and_write_back": time.perf_counter() - t_solved}
         logging.info("Bundle adjustment completed")

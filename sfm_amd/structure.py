@@ -7,6 +7,7 @@ point sharding used when the problem is split over several GPUs.
 """
 from __future__ import annotations
 
+import os
 from dataclasses import dataclass
 import numpy as np
 
@@ -111,13 +112,22 @@ def build_structure(cam_idx, pt_idx, n_cams, n_pts):
     i32 = lambda a: np.ascontiguousarray(a, dtype=np.int32)
     item_ptr, item_beg, item_end = _split_ranges(blk_ptr, ITEM_PAIRS)
     cch_ptr, cch_beg, cch_end = _split_ranges(cam_ptr, CHUNK_OBS)
-    # block row of every item -> group by row mod 8 (stable: rows, then blocks, stay in order inside a group)
+    # block row of every item -> 8 groups (stable: rows, then blocks, stay in order inside a group): row mod 8, or with
+    # SFM_XCD_GROUP=contig contiguous row ranges balanced by item count (the same rule as sfm_amd/csrc/problem.hip)
     n_blk_row = np.arange(n_cams, 0, -1, dtype=np.int64)                 # row c holds blocks (c, c..C-1)
     blk_row = np.repeat(np.arange(n_cams, dtype=np.int64), n_blk_row)
     item_row = np.repeat(blk_row, np.diff(item_ptr))
-    xcd_items = np.argsort(item_row % 8, kind="stable")
+    if os.environ.get("SFM_XCD_GROUP", "")[:1] == "c":
+        row_cnt = np.bincount(item_row, minlength=n_cams).astype(np.int64)
+        total = int(row_cnt.sum())
+        mid = np.cumsum(row_cnt) - row_cnt + row_cnt // 2
+        row_grp = np.minimum((mid * 8) // max(total, 1), 7) if total > 0 else np.zeros(n_cams, dtype=np.int64)
+    else:
+        row_grp = np.arange(n_cams, dtype=np.int64) % 8
+    item_grp = row_grp[item_row]
+    xcd_items = np.argsort(item_grp, kind="stable")
     xcd_ptr = np.zeros(9, dtype=np.int64)
-    np.cumsum(np.bincount(item_row % 8, minlength=8), out=xcd_ptr[1:])
+    np.cumsum(np.bincount(item_grp, minlength=8), out=xcd_ptr[1:])
     return BAStructure(int(n_cams), int(n_pts), i32(cam_idx), i32(pt_idx), i32(pt_ptr), i32(cam_ptr),
                        i32(cam_obs), i32(blk_ptr), i32(k[order]), i32(k2[order]),
                        i32(item_ptr), i32(item_beg), i32(item_end), i32(xcd_ptr), i32(xcd_items),
