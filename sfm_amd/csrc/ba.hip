@@ -822,15 +822,19 @@ __global__ __launch_bounds__(256) void k_cam_reduce_chunks(const int* __restrict
     part[(size_t)ch * 16 + tid] = t;
   }
 }
+// One wavefront per camera: lane = (slot s = lane >> 4, a = lane & 15); slot s adds the chunks s, s + 4, s + 8, ... in order and
+// the four slot sums are combined in fixed order - 5 dependent loads for a camera of 20 chunks where one thread per output
+// entry walked all 20 (11 us per call for 2,000 numbers, twice per damped solve).
 template <int D>
-__global__ void k_cam_reduce_final(int C, const int* __restrict__ cch_ptr, const double* __restrict__ part,
-                                   const double* __restrict__ base, double* __restrict__ out) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= C * D) return;
-  const int c = i / D, a = i - c * D;
+__global__ __launch_bounds__(256) void k_cam_reduce_final(int C, const int* __restrict__ cch_ptr, const double* __restrict__ part,
+                                                          const double* __restrict__ base, double* __restrict__ out) {
+  const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (c >= C) return;
+  const int lane = threadIdx.x & 63, s = lane >> 4, a = lane & 15;
   double t = 0.0;
-  for (int ch = cch_ptr[c]; ch < cch_ptr[c + 1]; ++ch) t += part[(size_t)ch * 16 + a];
-  out[i] = (base ? base[i] : 0.0) - t;
+  for (int ch = cch_ptr[c] + s; ch < cch_ptr[c + 1]; ch += 4) t += part[(size_t)ch * 16 + a];
+  const double t1 = __shfl(t, a + 16, 64), t2 = __shfl(t, a + 32, 64), t3 = __shfl(t, a + 48, 64);
+  if (s == 0 && a < D) out[c * D + a] = (base ? base[c * D + a] : 0.0) - ((t + t1) + (t2 + t3));
 }
 
 // tmp3[k][m] = sum_a G_k[m][a] p_c[cam(k)][a]
@@ -1257,7 +1261,7 @@ auto schur_items = [&](auto kp) {
     hipLaunchKernelGGL(k_schur_assemble<DD>, dim3(C, cdiv(C, 2)), dim3(256), 0, h->stream, C, p->item_ptr,
                        WS(L, sch_part), WS(L, B), WS(L, red_S));
     // the chunk partials of sum_k G_k e_j came out of the diagonal-block items above (or of the pass just launched)
-    hipLaunchKernelGGL(k_cam_reduce_final<DD>, dim3(cdiv(n, 256)), dim3(256), 0, h->stream, C, p->cch_ptr,
+    hipLaunchKernelGGL(k_cam_reduce_final<DD>, dim3(cdiv(C, 4)), dim3(256), 0, h->stream, C, p->cch_ptr,
                        WS(L, cch_part), WS(L, gc), WS(L, red_S) + (size_t)n * n);
     sfm_prof_end(h, SFM_PROF_SCHUR);
   });
@@ -1349,7 +1353,7 @@ enum { CGS_RR0 = 0, CGS_RR = 1, CGS_ITER = 2, CGS_FAIL = 3, CGS_DONE = 4,
 
 // E_c = chol(S_cc + alpha I); Einv[c] = E_c^-1 (lower, zeros above).  One thread per camera.
 template <int D>
-__global__ void k_diag_einv(int C, const double* __restrict__ S, int n, double alpha, double* __restrict__ Einv,
+__global__ __launch_bounds__(64) void k_diag_einv(int C, const double* __restrict__ S, int n, double alpha, double* __restrict__ Einv,
                             double* __restrict__ Efac /* E_c itself (lower), for warm starts: x~ = E^T y */, double* __restrict__ scal) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= C) return;
@@ -1369,33 +1373,39 @@ __global__ void k_diag_einv(int C, const double* __restrict__ S, int n, double a
     }
   if (bad) scal[CGS_FAIL] = 1.0;
 }
-// St[c][c2] = Einv_c (S[c][c2] + alpha [c == c2]) Einv_c2^T, one workgroup (128 threads) per block pair, both triangles
+// St[c][c2] = Einv_c (S[c][c2] + alpha [c == c2]) Einv_c2^T, both triangles.  One workgroup (128 threads, thread e < D*D owns
+// element e of a block) per block row c and SCALE_NB consecutive columns c2: a grid of one workgroup per block pair (40,000 at
+// 200 cameras) took 22 us for 32 MB of output - dispatch-bound.
+constexpr int SCALE_NB = 8;
 template <int D>
-__global__ __launch_bounds__(128) void k_scale_system(int n, const double* __restrict__ S, double alpha,
+__global__ __launch_bounds__(128) void k_scale_system(int n, int C, const double* __restrict__ S, double alpha,
                                                       const double* __restrict__ Einv, double* __restrict__ St) {
   __shared__ double sB[D * D], sT[D * D], sE1[D * D], sE2[D * D];
-  const int c = blockIdx.x, c2 = blockIdx.y, e = threadIdx.x;
+  const int c = blockIdx.x, e = threadIdx.x;
   const int a = e / D, b = e - a * D;
-  if (e < D * D) {
-    // only the lower triangle of S is read: it is the part the multi-rank exchange carries (sfm_ba_pack_system)
-    const int row = c * D + a, col = c2 * D + b;
-    sB[e] = (col <= row ? S[(size_t)row * n + col] : S[(size_t)col * n + row]) + ((c == c2 && a == b) ? alpha : 0.0);
-    sE1[e] = Einv[(size_t)c * D * D + e];
-    sE2[e] = Einv[(size_t)c2 * D * D + e];
-  }
-  __syncthreads();
-  if (e < D * D) {
-    double t = 0.0;
+  if (e < D * D) sE1[e] = Einv[(size_t)c * D * D + e];
+  for (int c2 = blockIdx.y * SCALE_NB; c2 < C && c2 < (int)(blockIdx.y + 1) * SCALE_NB; ++c2) {
+    __syncthreads();                                     // the previous block's sB / sT / sE2 have been read
+    if (e < D * D) {
+      // only the lower triangle of S is read: it is the part the multi-rank exchange carries (sfm_ba_pack_system)
+      const int row = c * D + a, col = c2 * D + b;
+      sB[e] = (col <= row ? S[(size_t)row * n + col] : S[(size_t)col * n + row]) + ((c == c2 && a == b) ? alpha : 0.0);
+      sE2[e] = Einv[(size_t)c2 * D * D + e];
+    }
+    __syncthreads();
+    if (e < D * D) {
+      double t = 0.0;
 #pragma unroll
-    for (int k = 0; k < D; ++k) t += sE1[a * D + k] * sB[k * D + b];        // Einv_c is lower: entries k > a are stored zeros
-    sT[e] = t;
-  }
-  __syncthreads();
-  if (e < D * D) {
-    double t = 0.0;
+      for (int k = 0; k < D; ++k) t += sE1[a * D + k] * sB[k * D + b];        // Einv_c is lower: entries k > a are stored zeros
+      sT[e] = t;
+    }
+    __syncthreads();
+    if (e < D * D) {
+      double t = 0.0;
 #pragma unroll
-    for (int k = 0; k < D; ++k) t += sT[a * D + k] * sE2[b * D + k];
-    St[(size_t)(c * D + a) * n + c2 * D + b] = t;
+      for (int k = 0; k < D; ++k) t += sT[a * D + k] * sE2[b * D + k];
+      St[(size_t)(c * D + a) * n + c2 * D + b] = t;
+    }
   }
 }
 // out_c = Einv_c v_c (transpose 0) or Einv_c^T v_c (transpose 1), optionally negated
@@ -1776,7 +1786,7 @@ extern "C" int sfm_ba_schur_solve(sfm_handle h, sfm_ba_problem p, double alpha, 
     SFM_HIP(h, hipMemsetAsync(WS(L, cg_scal), 0, 16 * sizeof(double), h->stream));
     DISPATCH_D(D, {
       hipLaunchKernelGGL(k_diag_einv<DD>, dim3(cdiv(C, 64)), dim3(64), 0, h->stream, C, S, n, alpha, WS(L, cg_Minv), WS(L, cg_M), WS(L, cg_scal));
-      hipLaunchKernelGGL(k_scale_system<DD>, dim3(C, C), dim3(128), 0, h->stream, n, S, alpha, WS(L, cg_Minv), dw.Lm);
+      hipLaunchKernelGGL(k_scale_system<DD>, dim3(C, cdiv(C, SCALE_NB)), dim3(128), 0, h->stream, n, C, S, alpha, WS(L, cg_Minv), dw.Lm);
       hipLaunchKernelGGL(k_block_mv<DD>, dim3(cdiv(n, 256)), dim3(256), 0, h->stream, C, WS(L, cg_Minv), S + (size_t)n * n, WS(L, cg_r), 0, 1.0);
     });
     int status = 1;
@@ -1831,7 +1841,7 @@ extern "C" int sfm_ba_schur_solve(sfm_handle h, sfm_ba_problem p, double alpha, 
       if (p->n_cchunks > 0)
         hipLaunchKernelGGL((k_cam_reduce_chunks<DD, double, GG>), dim3((unsigned)p->n_cchunks), dim3(256), 0, h->stream, p->cch_beg,
                            p->cch_end, p->cam_obs, p->pt_idx, WS(L, G), WS(L, v), WS(L, cch_part));
-      hipLaunchKernelGGL(k_cam_reduce_final<DD>, dim3(cdiv(n, 256)), dim3(256), 0, h->stream, C, p->cch_ptr,
+      hipLaunchKernelGGL(k_cam_reduce_final<DD>, dim3(cdiv(C, 4)), dim3(256), 0, h->stream, C, p->cch_ptr,
                          WS(L, cch_part), (const double*)nullptr, WS(L, red_q));
     });
   }
@@ -1955,7 +1965,7 @@ __global__ void k_cam_gg_final(int C, const int* __restrict__ cch_ptr, const dou
 }
 // Minv_c = (M_c + alpha I)^-1 by Cholesky, one thread per camera (D <= 10: 100 doubles of registers / scratch)
 template <int D>
-__global__ void k_precond_invert(int C, const double* __restrict__ M, double alpha, double* __restrict__ Minv,
+__global__ __launch_bounds__(64) void k_precond_invert(int C, const double* __restrict__ M, double alpha, double* __restrict__ Minv,
                                  double* __restrict__ scal) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= C) return;
@@ -2180,7 +2190,7 @@ extern "C" int sfm_ba_solve_pcg(sfm_handle h, sfm_ba_problem p, double alpha, in
       hipLaunchKernelGGL((k_cam_gg_chunks<DD, double, GG>), dim3((unsigned)p->n_cchunks), dim3(128), 0, h->stream, p->cch_beg, p->cch_end,
                          p->cam_obs, WS(L, G), WS(L, cbl_part));
     }
-    hipLaunchKernelGGL(k_cam_reduce_final<DD>, dim3(cdiv(n, 256)), dim3(256), 0, h->stream, C, p->cch_ptr, WS(L, cch_part), WS(L, gc),
+    hipLaunchKernelGGL(k_cam_reduce_final<DD>, dim3(cdiv(C, 4)), dim3(256), 0, h->stream, C, p->cch_ptr, WS(L, cch_part), WS(L, gc),
                        WS(L, tvec));
     hipLaunchKernelGGL(k_cam_gg_final<DD>, dim3(cdiv((int64_t)n * DD, 256)), dim3(256), 0, h->stream, C, p->cch_ptr, WS(L, cbl_part),
                        WS(L, B), WS(L, cg_M));
@@ -2211,7 +2221,7 @@ extern "C" int sfm_ba_solve_pcg(sfm_handle h, sfm_ba_problem p, double alpha, in
       if (p->n_cchunks > 0)
         hipLaunchKernelGGL((k_cam_reduce_chunks<DD, double, GG>), dim3((unsigned)p->n_cchunks), dim3(256), 0, h->stream, p->cch_beg,
                            p->cch_end, p->cam_obs, p->pt_idx, WS(L, G), WS(L, v), WS(L, cch_part));
-      hipLaunchKernelGGL(k_cam_reduce_final<DD>, dim3(cdiv(n, 256)), dim3(256), 0, h->stream, C, p->cch_ptr, WS(L, cch_part),
+      hipLaunchKernelGGL(k_cam_reduce_final<DD>, dim3(cdiv(C, 4)), dim3(256), 0, h->stream, C, p->cch_ptr, WS(L, cch_part),
                          (const double*)nullptr, WS(L, red_q));
     });
   }
