@@ -617,7 +617,7 @@ __global__ __launch_bounds__(256) void k_build_G(int64_t N, const int* __restric
 // row = (l>>4) + 4*reg.  Pair ids are loaded 64 at a time (coalesced) and broadcast with v_readlane so the
 // 16 gathers of 8 pairs are in flight together.  k_schur_assemble then sums the items of each block in
 // order (bitwise reproducible), adds B_c on the diagonal and writes the block and its mirror.
-template <int D, typename T, int GS, bool KPACK>
+template <int D, typename T, int GS, bool KPACK, bool NTK2>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) void k_schur_items(const int* __restrict__ xcd_ptr, const int* __restrict__ xcd_items,
                                                      const int* __restrict__ item_beg,
                                                      const int* __restrict__ item_end,
@@ -706,7 +706,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) voi
           ra[t] = ok ? *(const chunk_t*)(Gb + (size_t)k * BB + 16 * lc) : (chunk_t){0, 0, 0, 0};
           if (!DIAG) {
             const int k2 = __shfl(kk2, p & 63, 64);
-            rb[t] = ok ? *(const chunk_t*)(Gb + (size_t)k2 * BB + 16 * lc) : (chunk_t){0, 0, 0, 0};
+            // the k2 side of a block row is single-use: NTK2 asks for a non-temporal load (experiment, SFM_SCHUR_NT=1)
+            if (NTK2) rb[t] = ok ? __builtin_nontemporal_load((const chunk_t*)(Gb + (size_t)k2 * BB + 16 * lc)) : (chunk_t){0, 0, 0, 0};
+            else rb[t] = ok ? *(const chunk_t*)(Gb + (size_t)k2 * BB + 16 * lc) : (chunk_t){0, 0, 0, 0};
           }
         }
 #pragma unroll
@@ -1247,12 +1249,16 @@ extern "C" int sfm_ba_schur_build(sfm_handle h, sfm_ba_problem p, double alpha) 
       sfm_prof_begin(h, SFM_PROF_SCHUR_ITEMS);
       // SFM_SCHUR_KPACK=0: the one-pair-per-MFMA form (K = 3 of 4 used) for comparison
       static const bool kpack = !(getenv("SFM_SCHUR_KPACK") && getenv("SFM_SCHUR_KPACK")[0] == '0');
-auto schur_items = [&](auto kp) {
-        hipLaunchKernelGGL((k_schur_items<DD, double, GG, decltype(kp)::value>), dim3(8 * cdiv(p->xcd_max_items, 4)), dim3(256), 0, h->stream,
+      static const bool ntk2 = getenv("SFM_SCHUR_NT") && getenv("SFM_SCHUR_NT")[0] == '1';    // experiment: non-temporal k2-side loads
+      auto schur_items = [&](auto kp, auto nt) {
+        hipLaunchKernelGGL((k_schur_items<DD, double, GG, decltype(kp)::value, decltype(nt)::value>), dim3(8 * cdiv(p->xcd_max_items, 4)),
+                           dim3(256), 0, h->stream,
                            p->xcd_ptr, p->xcd_items, p->item_beg, p->item_end, p->pair_k, p->pair_k2, WS(L, G), WS(L, sch_part),
                            p->cam_idx, p->item_ptr, p->cch_ptr, C, WS(L, eobs), WS(L, cch_part), p->has_dup ? 0 : 1);
       };
-      if (kpack) schur_items(std::true_type{}); else schur_items(std::false_type{});
+      if (ntk2) schur_items(std::true_type{}, std::true_type{});
+      else if (kpack) schur_items(std::true_type{}, std::false_type{});
+      else schur_items(std::false_type{}, std::false_type{});
       sfm_prof_end(h, SFM_PROF_SCHUR_ITEMS);
     }
     if (p->has_dup && p->n_cchunks > 0)        // the chunk partials of sum_k G_k e_j by the camera-wise pass over G
@@ -1380,32 +1386,44 @@ constexpr int SCALE_NB = 8;
 template <int D>
 __global__ __launch_bounds__(128) void k_scale_system(int n, int C, const double* __restrict__ S, double alpha,
                                                       const double* __restrict__ Einv, double* __restrict__ St) {
-  __shared__ double sB[D * D], sT[D * D], sE1[D * D], sE2[D * D];
+  // all SCALE_NB blocks of the workgroup move through each stage together: three barriers per workgroup, not per block
+  __shared__ double sB[SCALE_NB][D * D], sT[SCALE_NB][D * D], sE2[SCALE_NB][D * D], sE1[D * D];
   const int c = blockIdx.x, e = threadIdx.x;
   const int a = e / D, b = e - a * D;
-  if (e < D * D) sE1[e] = Einv[(size_t)c * D * D + e];
-  for (int c2 = blockIdx.y * SCALE_NB; c2 < C && c2 < (int)(blockIdx.y + 1) * SCALE_NB; ++c2) {
-    __syncthreads();                                     // the previous block's sB / sT / sE2 have been read
-    if (e < D * D) {
-      // only the lower triangle of S is read: it is the part the multi-rank exchange carries (sfm_ba_pack_system)
-      const int row = c * D + a, col = c2 * D + b;
-      sB[e] = (col <= row ? S[(size_t)row * n + col] : S[(size_t)col * n + row]) + ((c == c2 && a == b) ? alpha : 0.0);
-      sE2[e] = Einv[(size_t)c2 * D * D + e];
-    }
-    __syncthreads();
-    if (e < D * D) {
-      double t = 0.0;
+  const int c2_0 = blockIdx.y * SCALE_NB;
+  const int nb = (C - c2_0) < SCALE_NB ? (C - c2_0) : SCALE_NB;
+  if (e < D * D) {
+    sE1[e] = Einv[(size_t)c * D * D + e];
 #pragma unroll
-      for (int k = 0; k < D; ++k) t += sE1[a * D + k] * sB[k * D + b];        // Einv_c is lower: entries k > a are stored zeros
-      sT[e] = t;
-    }
-    __syncthreads();
-    if (e < D * D) {
-      double t = 0.0;
+    for (int j = 0; j < SCALE_NB; ++j)
+      if (j < nb) {
+        // only the lower triangle of S is read: it is the part the multi-rank exchange carries (sfm_ba_pack_system)
+        const int c2 = c2_0 + j, row = c * D + a, col = c2 * D + b;
+        sB[j][e] = (col <= row ? S[(size_t)row * n + col] : S[(size_t)col * n + row]) + ((c == c2 && a == b) ? alpha : 0.0);
+        sE2[j][e] = Einv[(size_t)c2 * D * D + e];
+      }
+  }
+  __syncthreads();
+  if (e < D * D) {
 #pragma unroll
-      for (int k = 0; k < D; ++k) t += sT[a * D + k] * sE2[b * D + k];
-      St[(size_t)(c * D + a) * n + c2 * D + b] = t;
-    }
+    for (int j = 0; j < SCALE_NB; ++j)
+      if (j < nb) {
+        double t = 0.0;
+#pragma unroll
+        for (int k = 0; k < D; ++k) t += sE1[a * D + k] * sB[j][k * D + b];    // Einv_c is lower: entries k > a are stored zeros
+        sT[j][e] = t;
+      }
+  }
+  __syncthreads();
+  if (e < D * D) {
+#pragma unroll
+    for (int j = 0; j < SCALE_NB; ++j)
+      if (j < nb) {
+        double t = 0.0;
+#pragma unroll
+        for (int k = 0; k < D; ++k) t += sT[j][a * D + k] * sE2[j][b * D + k];
+        St[(size_t)(c * D + a) * n + (c2_0 + j) * D + b] = t;
+      }
   }
 }
 // out_c = Einv_c v_c (transpose 0) or Einv_c^T v_c (transpose 1), optionally negated
@@ -1550,15 +1568,26 @@ constexpr unsigned PR_SPIN_LIMIT = 1u << 17;      // passes over a thread's gran
 typedef unsigned long long pr_u64;
 #define PR_RLX_AGENT __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT
 
-template <int NC>
+// What used to be separate 4-us launches around a system, folded into the persistent kernel (all optional):
+struct PrFuse {
+  const double* Einv;      // non-null: the right-hand side arrives UNSCALED and rhs~ = E^-1 (rhs + rhs_b) is formed in the prologue
+  const double* rhs_b;     //   second summand (system of the q term: p_c + W C_a^-1 p_p pieces), may be null
+  double* pc_out;          // non-null (step system): p_c = -E^-T x~ is written here by workgroup 0 on convergence
+  const double* fin_pc;    // non-null (q system): the scalars of the damped solve are finished here on convergence
+  const double* fin_redq;  //   [n + 2]: ... | sum ||p_p||^2 | sum ||v||^2
+  double* fin_sc;          //   SFM_SC_PNORM2, SFM_SC_PQ, SFM_SC_CHOL_FAIL
+};
+
+template <int NC, int D>
 __global__ __launch_bounds__(256, 1) void k_cgs_persist(int n, double rtol2, int max_iter, unsigned salt,
                                                         const double* __restrict__ St, const double* __restrict__ rhs,
                                                         const double* __restrict__ x0 /* may be null: start from 0 */,
                                                         double* __restrict__ x_out, pr_u64* mail /* [2][n][2] granules */,
-                                                        pr_u64* abort_w, double* __restrict__ scal) {
+                                                        pr_u64* abort_w, double* __restrict__ scal, PrFuse f) {
   __shared__ double s_part[PR_ROWS][4];
   __shared__ double s_red[4];
   __shared__ int s_ok[4];
+  __shared__ double s_x[PR_MAX_N];                  // workgroup 0, epilogue: x~ for the block-wise back-transformation
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int row0 = (int)blockIdx.x * PR_ROWS;
   // this thread's slice of the workgroup's rows: registers for the whole solve
@@ -1570,12 +1599,29 @@ __global__ __launch_bounds__(256, 1) void k_cgs_persist(int n, double rtol2, int
       const int row = row0 + q, col = 2 * tid + 512 * c;            // n is even: col < n implies col + 1 < n
       sv[q][c] = (row < n && col < n) ? *(const double2*)(St + (size_t)row * n + col) : make_double2(0.0, 0.0);
     }
-  double xv[2 * NC], rv[2 * NC], pv[2 * NC];
+  double xv[2 * NC], rv[2 * NC], pv[2 * NC], bv[2 * NC];     // bv: the right-hand side itself (the q system's r~ . x~)
 #pragma unroll
   for (int c = 0; c < NC; ++c) {
     const int col = 2 * tid + 512 * c;
     const bool in = col < n;
-    rv[2 * c] = in ? rhs[col] : 0.0; rv[2 * c + 1] = in ? rhs[col + 1] : 0.0;
+    if (f.Einv) {
+      // rhs~_i = sum_k E^-1[cam][a][k] (rhs + rhs_b)[cam D + k]   (E^-1 lower triangular: the stored zeros above cost nothing here)
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        double t = 0.0;
+        if (in) {
+          const int i = col + u, cam = i / D, a = i - cam * D;
+          const double* e = f.Einv + (size_t)cam * D * D + a * D;
+          const double* r = rhs + cam * D;
+#pragma unroll
+          for (int k = 0; k < D; ++k) t += e[k] * (r[k] + (f.rhs_b ? f.rhs_b[cam * D + k] : 0.0));
+        }
+        rv[2 * c + u] = t;
+      }
+    } else {
+      rv[2 * c] = in ? rhs[col] : 0.0; rv[2 * c + 1] = in ? rhs[col + 1] : 0.0;
+    }
+    bv[2 * c] = rv[2 * c]; bv[2 * c + 1] = rv[2 * c + 1];
     xv[2 * c] = (in && x0) ? x0[col] : 0.0; xv[2 * c + 1] = (in && x0) ? x0[col + 1] : 0.0;
   }
   double rr0;
@@ -1655,6 +1701,54 @@ __global__ __launch_bounds__(256, 1) void k_cgs_persist(int n, double rtol2, int
       scal[CGS_RR0] = rr0; scal[CGS_RR] = rr; scal[CGS_ITER] = (double)it; scal[CGS_DONE] = done;
       if (fail != 0.0 && scal[CGS_FAIL] == 0.0) scal[CGS_FAIL] = fail;
     }
+    const bool converged = done == 1.0 && fail == 0.0 && rr <= rtol2 * rr0;
+    if (!converged || !(f.pc_out || f.fin_sc)) return;          // (workgroup-uniform)
+    if (f.pc_out) {
+      // p_c = -E^-T x~: entry (cam, a) needs the whole x~ block of its camera -> through LDS
+#pragma unroll
+      for (int c = 0; c < NC; ++c) {
+        const int col = 2 * tid + 512 * c;
+        if (col < n) { s_x[col] = xv[2 * c]; s_x[col + 1] = xv[2 * c + 1]; }
+      }
+      __syncthreads();
+#pragma unroll
+      for (int c = 0; c < NC; ++c) {
+        const int col = 2 * tid + 512 * c;
+        if (col < n) {
+#pragma unroll
+          for (int u = 0; u < 2; ++u) {
+            const int i = col + u, cam = i / D, a = i - cam * D;
+            const double* e = f.Einv + (size_t)cam * D * D;
+            double t = 0.0;
+#pragma unroll
+            for (int k = 0; k < D; ++k) t += e[k * D + a] * s_x[cam * D + k];
+            f.pc_out[i] = -t;
+          }
+        }
+      }
+    }
+    if (f.fin_sc) {
+      // the scalars of the damped solve (k_finish_solve_pcg): p^T (H + alpha I)^-1 p = rhs2~ . x~2 + sum ||v||^2
+      double t = 0.0, t2 = 0.0;
+#pragma unroll
+      for (int c = 0; c < NC; ++c) {
+        const int col = 2 * tid + 512 * c;
+        if (col < n) {
+          t += bv[2 * c] * xv[2 * c] + bv[2 * c + 1] * xv[2 * c + 1];
+          const double p0 = f.fin_pc[col], p1 = f.fin_pc[col + 1];
+          t2 += p0 * p0 + p1 * p1;
+        }
+      }
+      const double dot = block_sum256(t, s_red);
+      const double pc2 = block_sum256(t2, s_red);
+      if (tid == 0) {
+        const double pn2 = pc2 + f.fin_redq[n], pq = dot + f.fin_redq[n + 1];
+        f.fin_sc[SFM_SC_PNORM2] = pn2; f.fin_sc[SFM_SC_PQ] = pq;
+        double fl = scal[CGS_FAIL] != 0.0 ? 1.0 : 0.0;
+        if (fl == 0.0 && !(isfinite(pn2) && isfinite(pq))) fl = 3.0;
+        f.fin_sc[SFM_SC_CHOL_FAIL] = fl;
+      }
+    }
   };
 
   int round = 0;
@@ -1700,37 +1794,52 @@ __global__ __launch_bounds__(256, 1) void k_cgs_persist(int n, double rtol2, int
   finish(rr, it, rr <= rtol2 * rr0 ? 1.0 : 0.0, 0.0);
 }
 
-// x~ = S~^-1 rhs~ by CG; returns 0 converged / 1 not converged or broken (caller falls back to the factorisation)
-// x0_t: optional start vector (warm start; only the persistent kernel takes it).  mail: 4 n doubles of granule slots.
+// One persistent launch for a system (k_cgs_persist), in two halves so that the host never idles the GPU on its status:
+// cgs_persist_launch enqueues the kernel and the copy of its 8 status words into pinned memory (slot pin: SFM_PIN_CG1 /
+// SFM_PIN_CG2) and returns false when the kernel is not usable here (n, handle state, SFM_CGS_PERSIST=0);
+// cgs_persist_status interprets the copy once the caller knows it has arrived (an event behind it, or a later stream
+// synchronisation).  *ran = 0: the launch was abandoned - the caller takes the launch-per-iteration route (cgs_solve) with its
+// separate pre / post kernels; *status = 0: converged (and whatever `fuse` asked for has been done by workgroup 0).
+static bool cgs_persist_usable(sfm_ctx* h, int n) {
+  static const bool off = getenv("SFM_CGS_PERSIST") && getenv("SFM_CGS_PERSIST")[0] == '0';
+  return n <= PR_MAX_N && (n & 1) == 0 && !h->cgs_persist_off && !off;
+}
+static int cgs_persist_launch(sfm_ctx* h, int n, int D, const double* St, const double* rhs, const double* x0_t, double* x_t, double* mail,
+                              double* scal, double rtol, const PrFuse& fuse, int pin) {
+  const unsigned grid = (unsigned)cdiv(n, PR_ROWS);
+  const int nc = (int)cdiv(n, 512);
+  pr_u64* abort_w = (pr_u64*)(scal + 12);
+  h->cgs_seq = (h->cgs_seq + 1u) & 0xFFFFFFu;
+  if (h->cgs_seq == 0u) h->cgs_seq = 1u;           // tag 0 is what zeroed memory reads as
+  const unsigned salt = h->cgs_seq;
+  const double rtol2 = rtol * rtol;
+#define PR_LAUNCH(NC, DD_) hipLaunchKernelGGL((k_cgs_persist<NC, DD_>), dim3(grid), dim3(256), 0, h->stream, n, rtol2, CGS_MAX_ITER, salt, St, rhs, x0_t, x_t, (pr_u64*)mail, abort_w, scal, fuse)
+  if (D == 10) { if (nc <= 1) PR_LAUNCH(1, 10); else if (nc == 2) PR_LAUNCH(2, 10); else if (nc == 3) PR_LAUNCH(3, 10); else PR_LAUNCH(4, 10); }
+  else { if (nc <= 1) PR_LAUNCH(1, 6); else if (nc == 2) PR_LAUNCH(2, 6); else if (nc == 3) PR_LAUNCH(3, 6); else PR_LAUNCH(4, 6); }
+#undef PR_LAUNCH
+  SFM_HIP(h, hipMemcpyAsync(h->pinned + pin, scal, 8 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  SFM_LAUNCH_CHECK(h, "cgs_persist_launch");
+  return SFM_OK;
+}
+static void cgs_persist_status(sfm_ctx* h, int pin, int* iters_out, int* status, int* ran) {
+  const double* st = h->pinned + pin;
+  *ran = 0; *status = 1;
+  if (st[CGS_DONE] == -1.0) {                       // the launch was abandoned (a spin ran out)
+    h->cgs_persist_off = 1;
+    fprintf(stderr, "sfm_amd: the persistent CG launch was abandoned (grid not co-resident?); using one launch per iteration from now on\n");
+    return;
+  }
+  *ran = 1;
+  *iters_out += (int)st[CGS_ITER];
+  if (st[CGS_FAIL] == 0.0 && st[CGS_DONE] != 0.0) *status = 0;
+}
+
+// x~ = S~^-1 rhs~ by CG, one launch per iteration (k_cgs_iter); returns 0 converged / 1 not converged or broken (caller falls
+// back to the factorisation)
 static int cgs_solve(sfm_ctx* h, int n, const double* St, const double* rhs_t, double* x_t, double* vec, double* scal,
-                     double rtol, int* iters_out, int* status, const double* x0_t = nullptr, double* mail = nullptr) {
+                     double rtol, int* iters_out, int* status) {
   const double rtol2 = rtol * rtol;
   *status = 1;
-  // ---- one persistent launch per system (k_cgs_persist); SFM_CGS_PERSIST=0 keeps the launch-per-iteration kernel
-  if (mail && n <= PR_MAX_N && !h->cgs_persist_off) {
-    const char* pe = getenv("SFM_CGS_PERSIST");
-    if (!(pe && pe[0] == '0')) {
-      const unsigned grid = (unsigned)cdiv(n, PR_ROWS);
-      const int nc = (int)cdiv(n, 512);
-      pr_u64* abort_w = (pr_u64*)(scal + 12);
-      h->cgs_seq = (h->cgs_seq + 1u) & 0xFFFFFFu;
-      if (h->cgs_seq == 0u) h->cgs_seq = 1u;           // tag 0 is what zeroed memory reads as
-      const unsigned salt = h->cgs_seq;
-#define PR_LAUNCH(NC) hipLaunchKernelGGL((k_cgs_persist<NC>), dim3(grid), dim3(256), 0, h->stream, n, rtol2, CGS_MAX_ITER, salt, St, rhs_t, x0_t, x_t, (pr_u64*)mail, abort_w, scal)
-      if (nc <= 1) PR_LAUNCH(1); else if (nc == 2) PR_LAUNCH(2); else if (nc == 3) PR_LAUNCH(3); else PR_LAUNCH(4);
-#undef PR_LAUNCH
-      SFM_HIP(h, hipMemcpyAsync(h->pinned, scal, 8 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
-      SFM_HIP(h, hipStreamSynchronize(h->stream));
-      SFM_LAUNCH_CHECK(h, "cgs_solve (persistent)");
-      if (h->pinned[CGS_DONE] != -1.0) {               // -1: the launch was abandoned (a spin ran out) - fall through
-        *iters_out += (int)h->pinned[CGS_ITER];
-        if (h->pinned[CGS_FAIL] == 0.0 && h->pinned[CGS_DONE] != 0.0) *status = 0;
-        return SFM_OK;
-      }
-      h->cgs_persist_off = 1;
-      fprintf(stderr, "sfm_amd: the persistent CG launch was abandoned (grid not co-resident?); using one launch per iteration from now on\n");
-    }
-  }
   // (column chunks per thread, rows per workgroup): 128 registers of prefetched matrix per thread in the two larger shapes
   // four rows per workgroup: at n = 2000 that is 512 workgroups (two per CU) - 8 rows / 256 workgroups measured 6 % slower per
   // iteration, 2 rows / 1,024 workgroups 9 % slower (twice the redundant vector work).  SFM_CGS_ROWS=8 restores the old shapes.
@@ -1770,65 +1879,10 @@ static int cgs_solve(sfm_ctx* h, int n, const double* St, const double* rhs_t, d
   return SFM_OK;
 }
 
-extern "C" int sfm_ba_schur_solve(sfm_handle h, sfm_ba_problem p, double alpha, int want_q) {
-  Lay L; int rc = check_problem(h, p, &L); if (rc) return rc;
-  double* ws = (double*)p->workspace;
+// point back-substitution for the p_c in the workspace, and (want_q) the pieces of rhs2 = p_c - W C_a^-1 p_p
+static void launch_backsub(sfm_ctx* h, sfm_ba_problem p, const Lay& L, double* ws, int want_q) {
   const int C = p->n_cams, P = p->n_pts, D = p->cam_dim, n = C * D;
   const int64_t N = p->n_obs;
-  double* S = WS(L, red_S);
-  DenseWs dw; dense_ws_carve(WS(L, dense), n, &dw);
-  SFM_HIP(h, hipMemsetAsync(dw.flag, 0, sizeof(int), h->stream));
-  p->cg_state = 0;
-  p->cg_alpha = alpha;
-  if (p->camera_solver != SFM_CAMERA_SOLVER_CHOLESKY && n <= CGS_MAX_N && (n & 1) == 0) {
-    // S~ = E^-1 (S + alpha I) E^-T into the factor's buffer (S stays as it is: the fallback below needs it), r~ = E^-1 r
-    sfm_prof_begin(h, SFM_PROF_CHOL);
-    SFM_HIP(h, hipMemsetAsync(WS(L, cg_scal), 0, 16 * sizeof(double), h->stream));
-    DISPATCH_D(D, {
-      hipLaunchKernelGGL(k_diag_einv<DD>, dim3(cdiv(C, 64)), dim3(64), 0, h->stream, C, S, n, alpha, WS(L, cg_Minv), WS(L, cg_M), WS(L, cg_scal));
-      hipLaunchKernelGGL(k_scale_system<DD>, dim3(C, cdiv(C, SCALE_NB)), dim3(128), 0, h->stream, n, C, S, alpha, WS(L, cg_Minv), dw.Lm);
-      hipLaunchKernelGGL(k_block_mv<DD>, dim3(cdiv(n, 256)), dim3(256), 0, h->stream, C, WS(L, cg_Minv), S + (size_t)n * n, WS(L, cg_r), 0, 1.0);
-    });
-    int status = 1;
-    // Warm start (persistent kernel only).  Inside More's iteration consecutive damped systems differ only in alpha, and
-    // dp/dalpha = -(H + alpha I)^-1 p = -q is what the previous solve's second system produced: p_c(alpha') ~ p_c(alpha) -
-    // (alpha' - alpha) q_c(alpha), second-order accurate.  In the scaled variables x~_0 = E'^T y_0 with y_0 = -p_c.
-    double* warm = WS(L, cg_warm);                    // [pc_prev | qc_prev | x0 | scratch]
-    const double* x0 = nullptr;
-    static const bool warm_on = !(getenv("SFM_CGS_WARM") && getenv("SFM_CGS_WARM")[0] == '0');
-    if (warm_on && p->warm_pc_ok && std::fabs(alpha - p->warm_alpha) <= 0.5 * p->warm_alpha) {
-      hipLaunchKernelGGL(k_taylor, dim3(cdiv(n, 256)), dim3(256), 0, h->stream, n, warm, p->warm_qc_ok ? warm + n : (const double*)nullptr,
-                         alpha - p->warm_alpha, warm + 3 * (size_t)n);
-      DISPATCH_D(D, hipLaunchKernelGGL(k_block_mv<DD>, dim3(cdiv(n, 256)), dim3(256), 0, h->stream, C, WS(L, cg_M), warm + 3 * (size_t)n,
-                                       warm + 2 * (size_t)n, 1, -1.0));          // x~_0 = E^T (-p_c guess)
-      x0 = warm + 2 * (size_t)n;
-    }
-    p->warm_pc_ok = p->warm_qc_ok = 0;
-    rc = cgs_solve(h, n, dw.Lm, WS(L, cg_r), WS(L, cg_z), dw.LmT, WS(L, cg_scal), CGS_RTOL, &p->cg_iters, &status, x0, WS(L, cg_mail)); if (rc) return rc;
-    if (status == 0) {
-      DISPATCH_D(D, hipLaunchKernelGGL(k_block_mv<DD>, dim3(cdiv(n, 256)), dim3(256), 0, h->stream, C, WS(L, cg_Minv), WS(L, cg_z),
-                                       WS(L, pc), 1, -1.0));                      // p_c = -E^-T x~
-      if (warm_on) {
-        SFM_HIP(h, hipMemcpyAsync(warm, WS(L, pc), (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
-        p->warm_pc_ok = 1; p->warm_alpha = alpha;
-      }
-      p->cg_state = 1;
-    } else {
-      p->cg_fallbacks++;
-    }
-    sfm_prof_end(h, SFM_PROF_CHOL);
-  }
-  if (p->cg_state == 0) {
-    sfm_prof_begin(h, SFM_PROF_CHOL);
-    hipLaunchKernelGGL(k_add_diag, dim3(cdiv(n, 256)), dim3(256), 0, h->stream, S, n, alpha);
-    rc = dense_cholesky(h, S, n, n + 1, dw); if (rc) return rc;   // row n: r -> L^-1 r
-    sfm_prof_end(h, SFM_PROF_CHOL);
-    sfm_prof_begin(h, SFM_PROF_TRSV);
-    // p_c = -L^-T (L^-1 r)
-    hipLaunchKernelGGL(k_copy_neg, dim3(cdiv(n, 256)), dim3(256), 0, h->stream, dw.Lm + (size_t)n * n, WS(L, tvec), n, -1.0);
-    rc = dense_trsv(h, n, dw, WS(L, tvec), WS(L, pc), 1); if (rc) return rc;
-    sfm_prof_end(h, SFM_PROF_TRSV);
-  }
   sfm_prof_begin(h, SFM_PROF_BACKSUB);
   DISPATCH_DT(D, p->precision, hipLaunchKernelGGL((k_obs_Gtp<DD, double, GG>), dim3(cdiv(N * 3, 256)), dim3(256), 0, h->stream, N * 3,
                                                   p->cam_idx, WS(L, G), WS(L, pc), WS(L, tmp3)));
@@ -1846,44 +1900,106 @@ extern "C" int sfm_ba_schur_solve(sfm_handle h, sfm_ba_problem p, double alpha, 
     });
   }
   sfm_prof_end(h, SFM_PROF_BACKSUB);
+}
+
+extern "C" int sfm_ba_schur_solve(sfm_handle h, sfm_ba_problem p, double alpha, int want_q) {
+  Lay L; int rc = check_problem(h, p, &L); if (rc) return rc;
+  double* ws = (double*)p->workspace;
+  const int C = p->n_cams, D = p->cam_dim, n = C * D;
+  double* S = WS(L, red_S);
+  DenseWs dw; dense_ws_carve(WS(L, dense), n, &dw);
+  p->cg_state = 0;
+  p->cg2_pending = 0;
+  p->cg_alpha = alpha;
+  if (p->camera_solver != SFM_CAMERA_SOLVER_CHOLESKY && n <= CGS_MAX_N && (n & 1) == 0) {
+    // S~ = E^-1 (S + alpha I) E^-T into the factor's buffer (S stays as it is: the fallback below needs it), r~ = E^-1 r
+    sfm_prof_begin(h, SFM_PROF_CHOL);
+    SFM_HIP(h, hipMemsetAsync(WS(L, cg_scal), 0, 16 * sizeof(double), h->stream));
+    DISPATCH_D(D, {
+      hipLaunchKernelGGL(k_diag_einv<DD>, dim3(cdiv(C, 64)), dim3(64), 0, h->stream, C, S, n, alpha, WS(L, cg_Minv), WS(L, cg_M), WS(L, cg_scal));
+      hipLaunchKernelGGL(k_scale_system<DD>, dim3(C, cdiv(C, SCALE_NB)), dim3(128), 0, h->stream, n, C, S, alpha, WS(L, cg_Minv), dw.Lm);
+    });
+    int status = 1, ran = 0;
+    // Warm start (persistent kernel only; SFM_CGS_WARM=1, off by default: measured 13 % fewer iterations and no time saved).
+    // Inside More's iteration consecutive damped systems differ only in alpha, and dp/dalpha = -(H + alpha I)^-1 p = -q is
+    // what the previous solve's second system produced: p_c(alpha') ~ p_c(alpha) - (alpha' - alpha) q_c(alpha), second-order
+    // accurate.  In the scaled variables x~_0 = E'^T y_0 with y_0 = -p_c.
+    double* warm = WS(L, cg_warm);                    // [pc_prev | qc_prev | x0 | scratch]
+    const double* x0 = nullptr;
+    static const bool warm_on = getenv("SFM_CGS_WARM") && getenv("SFM_CGS_WARM")[0] == '1';
+    if (warm_on && p->warm_pc_ok && std::fabs(alpha - p->warm_alpha) <= 0.5 * p->warm_alpha) {
+      hipLaunchKernelGGL(k_taylor, dim3(cdiv(n, 256)), dim3(256), 0, h->stream, n, warm, p->warm_qc_ok ? warm + n : (const double*)nullptr,
+                         alpha - p->warm_alpha, warm + 3 * (size_t)n);
+      DISPATCH_D(D, hipLaunchKernelGGL(k_block_mv<DD>, dim3(cdiv(n, 256)), dim3(256), 0, h->stream, C, WS(L, cg_M), warm + 3 * (size_t)n,
+                                       warm + 2 * (size_t)n, 1, -1.0));          // x~_0 = E^T (-p_c guess)
+      x0 = warm + 2 * (size_t)n;
+    }
+    p->warm_pc_ok = p->warm_qc_ok = 0;
+    if (cgs_persist_usable(h, n)) {
+      // ONE persistent launch: r~ = E^-1 r in its prologue, p_c = -E^-T x~ in its epilogue.  The host needs its verdict
+      // (converged / fall back) but must not idle the GPU for it: the status words are copied to pinned memory, an event is
+      // recorded behind the copy, the back-substitution is enqueued on the assumption that the solve converged (it does: 0
+      // fallbacks in the bench schedules), and only then the host waits - for the event, not for the stream.
+      PrFuse fuse = {WS(L, cg_Minv), nullptr, WS(L, pc), nullptr, nullptr, nullptr};
+      rc = cgs_persist_launch(h, n, D, dw.Lm, S + (size_t)n * n, x0, WS(L, cg_z), WS(L, cg_mail), WS(L, cg_scal), CGS_RTOL, fuse, SFM_PIN_CG1);
+      if (rc) return rc;
+      SFM_HIP(h, hipEventRecord(h->cg_event, h->stream));
+      sfm_prof_end(h, SFM_PROF_CHOL);
+      launch_backsub(h, p, L, ws, want_q);
+      SFM_HIP(h, hipEventSynchronize(h->cg_event));
+      cgs_persist_status(h, SFM_PIN_CG1, &p->cg_iters, &status, &ran);
+      if (ran && status == 0) {
+        if (warm_on) {
+          SFM_HIP(h, hipMemcpyAsync(warm, WS(L, pc), (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+          p->warm_pc_ok = 1; p->warm_alpha = alpha;
+        }
+        p->cg_state = 1;
+        SFM_LAUNCH_CHECK(h, "sfm_ba_schur_solve");
+        return SFM_OK;
+      }
+      sfm_prof_begin(h, SFM_PROF_CHOL);             // not converged or abandoned: the routes below, then the back-substitution again
+    }
+    if (!ran) {                                       // launch per iteration, with the scaling of r and of the solution as kernels of their own
+      DISPATCH_D(D, hipLaunchKernelGGL(k_block_mv<DD>, dim3(cdiv(n, 256)), dim3(256), 0, h->stream, C, WS(L, cg_Minv), S + (size_t)n * n, WS(L, cg_r), 0, 1.0));
+      rc = cgs_solve(h, n, dw.Lm, WS(L, cg_r), WS(L, cg_z), dw.LmT, WS(L, cg_scal), CGS_RTOL, &p->cg_iters, &status); if (rc) return rc;
+      if (status == 0)
+        DISPATCH_D(D, hipLaunchKernelGGL(k_block_mv<DD>, dim3(cdiv(n, 256)), dim3(256), 0, h->stream, C, WS(L, cg_Minv), WS(L, cg_z),
+                                         WS(L, pc), 1, -1.0));                      // p_c = -E^-T x~
+    }
+    if (status == 0) {
+      if (warm_on) {
+        SFM_HIP(h, hipMemcpyAsync(warm, WS(L, pc), (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+        p->warm_pc_ok = 1; p->warm_alpha = alpha;
+      }
+      p->cg_state = 1;
+    } else {
+      p->cg_fallbacks++;
+    }
+    sfm_prof_end(h, SFM_PROF_CHOL);
+  }
+  if (p->cg_state == 0) {
+    sfm_prof_begin(h, SFM_PROF_CHOL);
+    SFM_HIP(h, hipMemsetAsync(dw.flag, 0, sizeof(int), h->stream));       // the factorisation's failure flag (k_finish_solve reads it)
+    hipLaunchKernelGGL(k_add_diag, dim3(cdiv(n, 256)), dim3(256), 0, h->stream, S, n, alpha);
+    rc = dense_cholesky(h, S, n, n + 1, dw); if (rc) return rc;   // row n: r -> L^-1 r
+    sfm_prof_end(h, SFM_PROF_CHOL);
+    sfm_prof_begin(h, SFM_PROF_TRSV);
+    // p_c = -L^-T (L^-1 r)
+    hipLaunchKernelGGL(k_copy_neg, dim3(cdiv(n, 256)), dim3(256), 0, h->stream, dw.Lm + (size_t)n * n, WS(L, tvec), n, -1.0);
+    rc = dense_trsv(h, n, dw, WS(L, tvec), WS(L, pc), 1); if (rc) return rc;
+    sfm_prof_end(h, SFM_PROF_TRSV);
+  }
+  launch_backsub(h, p, L, ws, want_q);
   SFM_LAUNCH_CHECK(h, "sfm_ba_schur_solve");
   return SFM_OK;
 }
 
-extern "C" int sfm_ba_finish_solve(sfm_handle h, sfm_ba_problem p, int want_q) {
-  Lay L; int rc = check_problem(h, p, &L); if (rc) return rc;
-  double* ws = (double*)p->workspace;
+// the q term from the factorisation (S intact in red_S): used when the CG on the second system did not converge
+static int finish_solve_by_factor(sfm_ctx* h, sfm_ba_problem p, const Lay& L, double* ws, int want_q, bool factor_first) {
   const int n = p->n_cams * p->cam_dim;
   DenseWs dw; dense_ws_carve(WS(L, dense), n, &dw);
-  if (p->cg_state == 1) {
-    // the camera system was solved by CG on the scaled system S~ (still in dw.Lm): p^T (H + alpha I)^-1 p needs
-    // rhs2^T S^-1 rhs2 = r~2^T x~2 with r~2 = E^-1 rhs2, S~ x~2 = r~2
-    const int C = p->n_cams, D = p->cam_dim;
-    int status = 0;
-    if (want_q) {
-      sfm_prof_begin(h, SFM_PROF_TRSV);
-      hipLaunchKernelGGL(k_add_vec, dim3(cdiv(n, 256)), dim3(256), 0, h->stream, WS(L, pc), WS(L, red_q), WS(L, tvec), n);
-      DISPATCH_D(D, hipLaunchKernelGGL(k_block_mv<DD>, dim3(cdiv(n, 256)), dim3(256), 0, h->stream, C, WS(L, cg_Minv), WS(L, tvec),
-                                       WS(L, cg_r), 0, 1.0));
-      status = 1;
-      rc = cgs_solve(h, n, dw.Lm, WS(L, cg_r), WS(L, cg_z), dw.LmT, WS(L, cg_scal), CGS_RTOL, &p->cg_iters, &status, nullptr, WS(L, cg_mail)); if (rc) return rc;
-      if (status == 0) {
-        hipLaunchKernelGGL(k_dot, dim3(1), dim3(1024), 0, h->stream, n, WS(L, cg_r), WS(L, cg_z), WS(L, cg_scal) + 8);
-        if (p->warm_pc_ok) {                         // q_c = E^-T x~_2 = -dp_c/dalpha for the next system's start vector
-          DISPATCH_D(D, hipLaunchKernelGGL(k_block_mv<DD>, dim3(cdiv(n, 256)), dim3(256), 0, h->stream, C, WS(L, cg_Minv), WS(L, cg_z),
-                                           WS(L, cg_warm) + n, 1, 1.0));
-          p->warm_qc_ok = 1;
-        }
-      }
-      sfm_prof_end(h, SFM_PROF_TRSV);
-    }
-    if (status == 0) {
-      hipLaunchKernelGGL(k_finish_solve_pcg, dim3(1), dim3(256), 0, h->stream, n, WS(L, pc), WS(L, red_q), want_q, WS(L, cg_scal) + 8,
-                         WS(L, cg_scal) + CGS_FAIL, WS(L, scalars));
-      SFM_LAUNCH_CHECK(h, "sfm_ba_finish_solve");
-      return SFM_OK;
-    }
-    // the second system did not converge: factor after all (S is intact) and take the q term from the factor
+  int rc;
+  if (factor_first) {
     p->cg_fallbacks++;
     p->cg_state = 0;
     SFM_HIP(h, hipMemsetAsync(dw.flag, 0, sizeof(int), h->stream));
@@ -1901,6 +2017,68 @@ extern "C" int sfm_ba_finish_solve(sfm_handle h, sfm_ba_problem p, int want_q) {
                      want_q, (const int*)dw.flag, WS(L, scalars));
   SFM_LAUNCH_CHECK(h, "sfm_ba_finish_solve");
   return SFM_OK;
+}
+
+extern "C" int sfm_ba_finish_solve(sfm_handle h, sfm_ba_problem p, int want_q) {
+  Lay L; int rc = check_problem(h, p, &L); if (rc) return rc;
+  double* ws = (double*)p->workspace;
+  const int n = p->n_cams * p->cam_dim;
+  DenseWs dw; dense_ws_carve(WS(L, dense), n, &dw);
+  if (p->cg_state == 1) {
+    // the camera system was solved by CG on the scaled system S~ (still in dw.Lm): p^T (H + alpha I)^-1 p needs
+    // rhs2^T S^-1 rhs2 = r~2^T x~2 with r~2 = E^-1 rhs2, S~ x~2 = r~2
+    const int C = p->n_cams, D = p->cam_dim;
+    int status = 0;
+    if (want_q) {
+      sfm_prof_begin(h, SFM_PROF_TRSV);
+      int ran = 0;
+      status = 1;
+      static const bool warm_on = getenv("SFM_CGS_WARM") && getenv("SFM_CGS_WARM")[0] == '1';
+      if (cgs_persist_usable(h, n)) {
+        // ONE persistent launch: r~2 = E^-1 (p_c + rhs2 pieces) in its prologue, r~2 . x~2 and the scalars of the solve in its
+        // epilogue.  Its verdict travels to pinned memory with the copy enqueued behind it and is looked at where the host
+        // synchronises anyway: in sfm_ba_read_scalars, which redoes this step from the factorisation if it has to.
+        PrFuse fuse = {WS(L, cg_Minv), WS(L, red_q), nullptr, WS(L, pc), WS(L, red_q), WS(L, scalars)};
+        rc = cgs_persist_launch(h, n, D, dw.Lm, WS(L, pc), nullptr, WS(L, cg_z), WS(L, cg_mail), WS(L, cg_scal), CGS_RTOL, fuse, SFM_PIN_CG2);
+        if (rc) return rc;
+        if (!warm_on) {
+          p->cg2_pending = 1;
+          sfm_prof_end(h, SFM_PROF_TRSV);
+          return SFM_OK;
+        }
+        SFM_HIP(h, hipStreamSynchronize(h->stream));
+        cgs_persist_status(h, SFM_PIN_CG2, &p->cg_iters, &status, &ran);
+        if (ran && status == 0) {
+          if (p->warm_pc_ok) {                       // q_c = E^-T x~_2 = -dp_c/dalpha for the next system's start vector
+            DISPATCH_D(D, hipLaunchKernelGGL(k_block_mv<DD>, dim3(cdiv(n, 256)), dim3(256), 0, h->stream, C, WS(L, cg_Minv), WS(L, cg_z),
+                                             WS(L, cg_warm) + n, 1, 1.0));
+            p->warm_qc_ok = 1;
+          }
+          sfm_prof_end(h, SFM_PROF_TRSV);
+          SFM_LAUNCH_CHECK(h, "sfm_ba_finish_solve");
+          return SFM_OK;                             // the scalars were written by the kernel's epilogue
+        }
+      }
+      if (!ran) {
+        hipLaunchKernelGGL(k_add_vec, dim3(cdiv(n, 256)), dim3(256), 0, h->stream, WS(L, pc), WS(L, red_q), WS(L, tvec), n);
+        DISPATCH_D(D, hipLaunchKernelGGL(k_block_mv<DD>, dim3(cdiv(n, 256)), dim3(256), 0, h->stream, C, WS(L, cg_Minv), WS(L, tvec),
+                                         WS(L, cg_r), 0, 1.0));
+        rc = cgs_solve(h, n, dw.Lm, WS(L, cg_r), WS(L, cg_z), dw.LmT, WS(L, cg_scal), CGS_RTOL, &p->cg_iters, &status); if (rc) return rc;
+        if (status == 0)
+          hipLaunchKernelGGL(k_dot, dim3(1), dim3(1024), 0, h->stream, n, WS(L, cg_r), WS(L, cg_z), WS(L, cg_scal) + 8);
+      }
+      sfm_prof_end(h, SFM_PROF_TRSV);
+    }
+    if (status == 0) {
+      hipLaunchKernelGGL(k_finish_solve_pcg, dim3(1), dim3(256), 0, h->stream, n, WS(L, pc), WS(L, red_q), want_q, WS(L, cg_scal) + 8,
+                         WS(L, cg_scal) + CGS_FAIL, WS(L, scalars));
+      SFM_LAUNCH_CHECK(h, "sfm_ba_finish_solve");
+      return SFM_OK;
+    }
+    // the second system did not converge: factor after all (S is intact) and take the q term from the factor
+    return finish_solve_by_factor(h, p, L, ws, want_q, true);
+  }
+  return finish_solve_by_factor(h, p, L, ws, want_q, false);
 }
 
 // ------------------------------------------------------------------------------------ implicit-Schur PCG
@@ -2318,6 +2496,19 @@ extern "C" int sfm_ba_read_scalars(sfm_handle h, sfm_ba_problem p, double* out_h
   double* ws = (double*)p->workspace;
   SFM_HIP(h, hipMemcpyAsync(h->pinned, WS(L, scalars), SFM_SC_COUNT * sizeof(double), hipMemcpyDeviceToHost, h->stream));
   SFM_HIP(h, hipStreamSynchronize(h->stream));
+  if (p->cg2_pending) {
+    // the verdict of the persistent CG on the second system of the last damped solve (sfm_ba_finish_solve) arrived with this
+    // synchronisation; if that system did not converge - or its launch was abandoned - the q term is redone from the
+    // factorisation now (no exchange between ranks is involved: red_q has been reduced already)
+    p->cg2_pending = 0;
+    int status = 1, ran = 0;
+    cgs_persist_status(h, SFM_PIN_CG2, &p->cg_iters, &status, &ran);
+    if (!(ran && status == 0)) {
+      if ((rc = finish_solve_by_factor(h, p, L, ws, 1, true))) return rc;
+      SFM_HIP(h, hipMemcpyAsync(h->pinned, WS(L, scalars), SFM_SC_COUNT * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+      SFM_HIP(h, hipStreamSynchronize(h->stream));
+    }
+  }
   memcpy(out_host, h->pinned, SFM_SC_COUNT * sizeof(double));
   return SFM_OK;
 }

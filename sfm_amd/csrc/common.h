@@ -7,6 +7,9 @@
 #include "sfm_amd.h"
 
 #define SFM_PROF_RING 128
+#define SFM_PINNED_DOUBLES 64
+#define SFM_PIN_CG1 32
+#define SFM_PIN_CG2 40
 struct sfm_prof_slot {
   hipEvent_t start[SFM_PROF_RING], stop[SFM_PROF_RING];
   int pending;             // recorded, not yet folded into total_ms
@@ -18,7 +21,9 @@ struct sfm_ctx {
   int device;
   hipStream_t stream;
   char err[512];
-  double* pinned;          // SFM_SC_COUNT doubles of pinned host memory for scalar read-back
+  double* pinned;          // SFM_PINNED_DOUBLES of pinned host memory: [0, SFM_SC_COUNT) scalar read-back, then the status words
+                           // of the two camera-CG systems of a damped solve (SFM_PIN_CG1, SFM_PIN_CG2: 8 doubles each)
+  hipEvent_t cg_event;     // recorded behind the status copy of the first system (sfm_ba_schur_solve waits for it, not for the stream)
   int profiling;
   sfm_prof_slot prof[SFM_PROF_COUNT];
   void* scratch;           // growable device scratch for calls that take no workspace (sfm_scratch)

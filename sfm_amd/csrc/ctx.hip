@@ -27,8 +27,15 @@ extern "C" int sfm_create(int device, sfm_handle* out) {
   h->cgs_seq = 0;
   h->cgs_persist_off = 0;
   memset(h->prof, 0, sizeof(h->prof));
-  if ((e = hipHostMalloc((void**)&h->pinned, SFM_SC_COUNT * sizeof(double), hipHostMallocDefault)) != hipSuccess) {
+  if ((e = hipHostMalloc((void**)&h->pinned, SFM_PINNED_DOUBLES * sizeof(double), hipHostMallocDefault)) != hipSuccess) {
     fprintf(stderr, "sfm_create: hipHostMalloc -> %s\n", hipGetErrorString(e));
+    delete h;
+    return SFM_ERR_HIP;
+  }
+  h->cg_event = nullptr;
+  if ((e = hipEventCreateWithFlags(&h->cg_event, hipEventDisableTiming)) != hipSuccess) {
+    fprintf(stderr, "sfm_create: hipEventCreate -> %s\n", hipGetErrorString(e));
+    (void)hipHostFree(h->pinned);
     delete h;
     return SFM_ERR_HIP;
   }
@@ -93,6 +100,7 @@ extern "C" void sfm_destroy(sfm_handle h) {
         (void)hipEventDestroy(h->prof[k].start[i]);
         (void)hipEventDestroy(h->prof[k].stop[i]);
       }
+  if (h->cg_event) (void)hipEventDestroy(h->cg_event);
   if (h->pinned) (void)hipHostFree(h->pinned);
   if (h->scratch) (void)hipFree(h->scratch);
   delete h;
