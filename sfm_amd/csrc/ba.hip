@@ -361,10 +361,31 @@ __global__ __launch_bounds__(256) void k_cam_blocks_chunks(const int* __restrict
   __shared__ double s_tile[4][16 * 17];
   const int ch = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int beg = cch_beg[ch], cnt = cch_end[ch] - beg;
-  for (int i = tid; i < cnt * W; i += 256) {
-    const int o = i / W, q = i - o * W;
-    const int k = cam_obs[beg + o];
-    s[o * LDW + q] = (q < 2 * D) ? (double)recA[(size_t)k * (2 * D) + q] : (double)recB[(size_t)k * 8 + 6 + (q - 2 * D)];
+  // gather of the chunk's rows: 16 lanes per observation, each one PAIR of values (16 bytes in float64) - the D pairs of the
+  // Jc~ rows and the pair f~ - so a row arrives in one load instruction per wavefront of four observations, and the loads of
+  // four trips are in flight together.  (One value per thread, 22 threads per observation: 150 us per linearisation at cfg4
+  // for 176 MB - a quarter of the rate of the other passes over the records.)
+  {
+    typedef T pair_t __attribute__((ext_vector_type(2)));
+    const int slot = tid >> 4, l16 = tid & 15;
+    const bool live = l16 <= D;                              // pairs 0 .. D-1: Jc~, pair D: f~
+    for (int o0 = 0; o0 < cnt; o0 += 64) {
+      pair_t v[4];
+#pragma unroll
+      for (int it = 0; it < 4; ++it) {
+        const int o = o0 + it * 16 + slot;
+        v[it] = (pair_t)(T)0;
+        if (live && o < cnt) {
+          const int k = cam_obs[beg + o];
+          v[it] = l16 < D ? *(const pair_t*)(recA + (size_t)k * (2 * D) + 2 * l16) : *(const pair_t*)(recB + (size_t)k * 8 + 6);
+        }
+      }
+#pragma unroll
+      for (int it = 0; it < 4; ++it) {
+        const int o = o0 + it * 16 + slot;
+        if (live && o < cnt) { s[o * LDW + 2 * l16] = (double)v[it].x; s[o * LDW + 2 * l16 + 1] = (double)v[it].y; }
+      }
+    }
   }
   __syncthreads();
   const int col = lane & 15, kq = lane >> 4;             // operand column (0..D-1: Jc~, D: f~), k slot
@@ -796,31 +817,47 @@ __global__ __launch_bounds__(256) void k_schur_assemble(int C, const int* __rest
 }
 
 // out[c][a] = (base ? base[c][a] : 0) - sum_{k in camera c} sum_m G_k[m][a] vec[pt(k)][m]
-// Camera lists are cut into chunks of <= 256 observations: one workgroup per chunk (16 observation slots x
-// 16 lanes over a), slots reduced through LDS in fixed order; k_cam_reduce_final sums a camera's chunks in order.
+// Camera lists are cut into chunks of <= 256 observations: one workgroup per chunk.  A G block is fetched as 16-byte pieces,
+// one per lane - 16 lanes take one whole block in ONE load instruction (GS = 32: 256 contiguous bytes = two full lines; the
+// round-2 form issued three 8-byte loads per lane, 80 bytes apart, for the same block) - so a wavefront covers four
+// observations per trip.  Lane l16 of a group holds the elements e = 2 l16, 2 l16 + 1 of the block, i.e. (m, a), (m, a + 1)
+// with m = e / D, a = e % D (D is even: a pair never straddles two m), multiplies them with vec[pt][m] and keeps its two
+// running sums; at the end the sums of equal a are added over m, the four groups and the four wavefronts in fixed order.
 template <int D, typename T, int GS>
 __global__ __launch_bounds__(256) void k_cam_reduce_chunks(const int* __restrict__ cch_beg, const int* __restrict__ cch_end,
                                                            const int* __restrict__ cam_obs, const int* __restrict__ pt_idx,
                                                            const T* __restrict__ G, const double* __restrict__ vec,
                                                            double* __restrict__ part) {
-  __shared__ double s[16 * 16];
-  const int ch = blockIdx.x, tid = threadIdx.x;
-  const int slot = tid >> 4, a = tid & 15;
-  double acc = 0.0;
-  if (a < D) {
-    for (int i = cch_beg[ch] + slot; i < cch_end[ch]; i += 16) {
-      const int k = cam_obs[i];
-      const T* g = G + (size_t)k * GS + a;
-      const double* v = vec + (size_t)pt_idx[k] * 3;
-      acc += (double)g[0] * v[0] + (double)g[D] * v[1] + (double)g[2 * D] * v[2];
+  static_assert(D % 2 == 0 && GS % 2 == 0 && GS <= 32, "16-byte pieces of a block: one per lane of a 16-lane group");
+  typedef T pair_t __attribute__((ext_vector_type(2)));
+  __shared__ double s[4][4][32];                      // [wave][group][element]
+  const int ch = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int grp = lane >> 4, l16 = lane & 15;
+  const int e0 = 2 * l16;
+  const bool live = e0 < 3 * D;
+  const int m = live ? e0 / D : 0;
+  double acc0 = 0.0, acc1 = 0.0;
+  const int beg = cch_beg[ch], end = cch_end[ch];
+  for (int i = beg + w * 4 + grp; i < end; i += 16) {
+    const int k = cam_obs[i];
+    const double vm = vec[(size_t)pt_idx[k] * 3 + m];
+    if (live) {
+      const pair_t g = *(const pair_t*)(G + (size_t)k * GS + e0);
+      acc0 += (double)g.x * vm; acc1 += (double)g.y * vm;
     }
   }
-  s[slot * 16 + a] = acc;
+  s[w][grp][e0] = acc0; s[w][grp][e0 + 1] = acc1;
   __syncthreads();
   if (tid < 16) {
     double t = 0.0;
+    if (tid < D) {
 #pragma unroll
-    for (int q = 0; q < 16; ++q) t += s[q * 16 + tid];
+      for (int mm = 0; mm < 3; ++mm)
+#pragma unroll
+        for (int ww = 0; ww < 4; ++ww)
+#pragma unroll
+          for (int gg = 0; gg < 4; ++gg) t += s[ww][gg][mm * D + tid];
+    }
     part[(size_t)ch * 16 + tid] = t;
   }
 }
@@ -840,19 +877,46 @@ __global__ __launch_bounds__(256) void k_cam_reduce_final(int C, const int* __re
 }
 
 // tmp3[k][m] = sum_a G_k[m][a] p_c[cam(k)][a]
+// 16 lanes per observation, each with one 16-byte piece of the block (see k_cam_reduce_chunks): the whole block in one
+// coalesced load, p_c[cam] as 16-byte pieces too; the D / 2 products of equal m are summed through LDS in fixed order.
+constexpr int GTP_OBS = 64;                           // observations per workgroup of k_obs_Gtp (four trips of 16)
 template <int D, typename T, int GS>
-__global__ __launch_bounds__(256) void k_obs_Gtp(int64_t total, const int* __restrict__ cam_idx,
+__global__ __launch_bounds__(256) void k_obs_Gtp(int64_t N, const int* __restrict__ cam_idx,
                                                  const T* __restrict__ G,
                                                  const double* __restrict__ pc, double* __restrict__ tmp3) {
-  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (i >= total) return;
-  const int64_t k = i / 3;
-  const T* g = G + (size_t)k * GS + (size_t)(i - 3 * k) * D;
-  const double* p = pc + (size_t)cam_idx[k] * D;
-  double t = 0.0;
+  static_assert(D % 2 == 0 && GS % 2 == 0 && GS <= 32, "16-byte pieces of a block: one per lane of a 16-lane group");
+  typedef T pair_t __attribute__((ext_vector_type(2)));
+  __shared__ double s[GTP_OBS][17];                   // [observation of the workgroup][lane of its group]
+  const int tid = threadIdx.x, slot = tid >> 4, l16 = tid & 15;
+  const int64_t k0 = (int64_t)blockIdx.x * GTP_OBS;
+  const int e0 = 2 * l16;
+  const int a = e0 % D;
+  const bool live = e0 < 3 * D;
+  pair_t g[GTP_OBS / 16];
+  int cam[GTP_OBS / 16];
 #pragma unroll
-  for (int a = 0; a < D; ++a) t += (double)g[a] * p[a];
-  tmp3[i] = t;
+  for (int it = 0; it < GTP_OBS / 16; ++it) {           // every load of the workgroup in flight before the first use
+    const int64_t k = k0 + it * 16 + slot;
+    const bool ok = live && k < N;
+    g[it] = ok ? *(const pair_t*)(G + (size_t)k * GS + e0) : (pair_t)(T)0;
+    cam[it] = ok ? cam_idx[k] : 0;
+  }
+#pragma unroll
+  for (int it = 0; it < GTP_OBS / 16; ++it) {
+    const double2 p = *(const double2*)(pc + (size_t)cam[it] * D + a);
+    s[it * 16 + slot][l16] = (double)g[it].x * p.x + (double)g[it].y * p.y;
+  }
+  __syncthreads();
+  if (tid < 3 * GTP_OBS) {                            // GTP_OBS x 3 values, one contiguous run
+    const int sl = tid / 3, mm = tid - 3 * sl;
+    const int64_t kk = k0 + sl;
+    if (kk < N) {
+      double u = 0.0;
+#pragma unroll
+      for (int j = 0; j < D / 2; ++j) u += s[sl][mm * (D / 2) + j];
+      tmp3[kk * 3 + mm] = u;
+    }
+  }
 }
 
 // p_pj = -M^T (e_j + sum_track tmp3),  v_j = M p_pj ; block partials of ||p_p||^2 and ||v||^2.
@@ -1884,7 +1948,7 @@ static void launch_backsub(sfm_ctx* h, sfm_ba_problem p, const Lay& L, double* w
   const int C = p->n_cams, P = p->n_pts, D = p->cam_dim, n = C * D;
   const int64_t N = p->n_obs;
   sfm_prof_begin(h, SFM_PROF_BACKSUB);
-  DISPATCH_DT(D, p->precision, hipLaunchKernelGGL((k_obs_Gtp<DD, double, GG>), dim3(cdiv(N * 3, 256)), dim3(256), 0, h->stream, N * 3,
+  DISPATCH_DT(D, p->precision, hipLaunchKernelGGL((k_obs_Gtp<DD, double, GG>), dim3(cdiv(N, GTP_OBS)), dim3(256), 0, h->stream, N,
                                                   p->cam_idx, WS(L, G), WS(L, pc), WS(L, tmp3)));
   hipLaunchKernelGGL(k_backsub, dim3((unsigned)L.nblk_pt), dim3(256), 0, h->stream, P, p->pt_ptr, WS(L, tmp3),
                      WS(L, Linv), WS(L, e), WS(L, pp), WS(L, v), WS(L, part_pt));
@@ -2275,7 +2339,7 @@ struct Pcg {
     const int C = p->n_cams, P = p->n_pts, D = p->cam_dim, n = C * D;
     const int64_t N = p->n_obs;
     DISPATCH_DT(D, p->precision, {
-      hipLaunchKernelGGL((k_obs_Gtp<DD, double, GG>), dim3(cdiv(N * 3, 256)), dim3(256), 0, h->stream, N * 3, p->cam_idx, WS(L, G), v, WS(L, tmp3));
+      hipLaunchKernelGGL((k_obs_Gtp<DD, double, GG>), dim3(cdiv(N, GTP_OBS)), dim3(256), 0, h->stream, N, p->cam_idx, WS(L, G), v, WS(L, tmp3));
       hipLaunchKernelGGL(k_track_sum, dim3(cdiv(P, 256)), dim3(256), 0, h->stream, P, p->pt_ptr, WS(L, tmp3), WS(L, v));
       if (p->n_cchunks > 0)
         hipLaunchKernelGGL((k_cam_reduce_chunks<DD, double, GG>), dim3((unsigned)p->n_cchunks), dim3(256), 0, h->stream, p->cch_beg,
@@ -2389,7 +2453,7 @@ extern "C" int sfm_ba_solve_pcg(sfm_handle h, sfm_ba_problem p, double alpha, in
   hipLaunchKernelGGL(k_copy_neg, dim3(cdiv(n, 256)), dim3(256), 0, h->stream, WS(L, y), WS(L, pc), n, -1.0);
   sfm_prof_end(h, SFM_PROF_CHOL);
   sfm_prof_begin(h, SFM_PROF_BACKSUB);
-  DISPATCH_DT(D, p->precision, hipLaunchKernelGGL((k_obs_Gtp<DD, double, GG>), dim3(cdiv(N * 3, 256)), dim3(256), 0, h->stream, N * 3,
+  DISPATCH_DT(D, p->precision, hipLaunchKernelGGL((k_obs_Gtp<DD, double, GG>), dim3(cdiv(N, GTP_OBS)), dim3(256), 0, h->stream, N,
                                                   p->cam_idx, WS(L, G), WS(L, pc), WS(L, tmp3)));
   hipLaunchKernelGGL(k_backsub, dim3((unsigned)L.nblk_pt), dim3(256), 0, h->stream, P, p->pt_ptr, WS(L, tmp3), WS(L, Linv), WS(L, e),
                      WS(L, pp), WS(L, v), WS(L, part_pt));
