@@ -255,15 +255,26 @@ def main():
     cg_on = args.camera_solver != "cholesky" and n_sys <= 4096
     cam_roofs = []
     if cg_on and "chol" in kernels:
-        # both slots of the camera solve hold CG solves here (chol: the step system, trsv: the system of the q term)
+        # both slots of the camera solve hold CG solves here (chol: the step system incl. its scaling kernels, trsv: the system
+        # of the q term).  n <= 2048: ONE persistent launch per system (k_cgs_persist: the matrix rows live in registers, so S~
+        # is read from memory once per system; what bounds it is the all-gather of S~ p between workgroups, once per iteration)
         its, fb = profd["camera_cg"]
         n_systems = kernels["chol"]["launches"] + kernels.get("trsv", {}).get("launches", 0)
         per_system = its / max(n_systems, 1)
-        cam_roofs.append(roof("k_cgs_iter: CG on the block-scaled camera system, n = %d (one launch per iteration)" % n_sys, "hbm",
-                              per_system * n_sys * n_sys * 8.0, 1e9, HBM_PEAK_GBS, "GB/s", "chol",
-                              note="%.1f iterations per system on average (relative residual 1e-13), each streams S~ (n^2 doubles, "
-                                   "L2 / Infinity-Cache resident) once: launch-latency bound, ~8 us per iteration; %d fallbacks to "
-                                   "the factorisation" % (per_system, fb)))
+        persistent = n_sys <= 2048 and os.environ.get("SFM_CGS_PERSIST", "1") != "0"
+        r = roof(("k_cgs_persist" if persistent else "k_cgs_iter") + ": CG on the block-scaled camera system, n = %d" % n_sys, "hbm",
+                 (1.0 if persistent else per_system) * n_sys * n_sys * 8.0, 1e9, HBM_PEAK_GBS, "GB/s", "trsv" if "trsv" in kernels else "chol",
+                 note="%.1f iterations per system on average (relative residual 1e-13); %d fallbacks to the factorisation.  "
+                      % (per_system, fb) + ("Exchange-latency bound, not bandwidth bound: one launch per system, S~ (n^2 doubles) is read "
+                      "once into registers, every iteration all-gathers the n entries of S~ p between the n / 8 workgroups through 8-byte "
+                      "granules; `achieved` prices that single read of S~ against HBM and is small by construction - see us_per_iteration "
+                      "(slot of the second system: prologue + iterations + epilogue)" if persistent else
+                      "one launch per iteration, each streams S~ (n^2 doubles, L2 / Infinity-Cache resident) once: launch-latency bound"))
+        if r:
+            r["iterations_per_system"] = round(per_system, 2)
+            r["us_per_iteration"] = round(r["avg_us"] / max(per_system, 1.0), 2)
+            r["time_share"] = kernels["chol"]["share"] + kernels.get("trsv", {}).get("share", 0.0)
+        cam_roofs.append(r)
     else:
         cam_roofs.append(roof("k_chol_diag + k_chol_step (+ k_syrk_lower): bordered Cholesky of the reduced camera system, n = %d" % n_sys,
                               "mfma", n_sys ** 3 / 3.0, 1e12, FP64_MFMA_PEAK_TFLOPS, "TFLOP/s", "chol",
@@ -274,15 +285,17 @@ def main():
     # L2 (every block ~10 times) is reported beside it as l2_gather_rate, never as `frac`.
     n_loc, n_pairs = main["n_obs_local"], main["n_pairs"]
     schur_unique = n_loc * 3 * d * 8 + n_pairs * 8.0
-    schur_gathered = (2.0 * n_pairs - n_loc) * 3 * d * 8 + n_loc * 24.0
+    g_block = 256 if (d == 10 and os.environ.get("SFM_G_PAD", "1") != "0") else 3 * d * 8      # bytes a pulled G block occupies
+    schur_gathered = (2.0 * n_pairs - n_loc) * g_block + n_loc * 24.0
     roofs = cam_roofs + [
         roof("k_schur_items (S blocks = -sum G_k G_k2^T per camera pair, f64 MFMA)", "hbm", schur_unique, 1e9, HBM_PEAK_GBS, "GB/s",
              "schur_items", "k_schur_items",
              note="a gather: `achieved` / `frac` price the unique data of a launch (%.0f MB of G + %.0f MB of pair indices) "
                   "against the HBM peak; `traffic` is what leaves the L2s for the Infinity Cache / HBM (PMC), `wasted_traffic` = "
                   "traffic / unique bytes, `l2_gather_rate` the rate at which G blocks are pulled through L2 (2 x %d B per camera "
-                  "pair), `flop_frac` the useful 2 x 3 x d x d FLOP per pair against the fp64 MFMA rate" % (
-                      n_loc * 3 * d * 8 / 1e6, n_pairs * 8 / 1e6, 3 * d * 8)),
+                  "pair: blocks are stored at a 256-byte stride for d = 10 so that one is exactly two 128-byte lines), `flop_frac` the "
+                  "useful 2 x 3 x d x d FLOP per pair against the fp64 MFMA rate" % (
+                      n_loc * 3 * d * 8 / 1e6, n_pairs * 8 / 1e6, g_block)),
         roof("k_lin_obs (residual + 2x(%d+3) Jacobian + Huber scaling)" % d, "hbm", float(bytes_per_obs) * main["n_obs_local"],
              1e9, HBM_PEAK_GBS, "GB/s", "lin_obs", "k_lin_obs"),
     ]

@@ -125,10 +125,12 @@ int sfm_match_f32_to_u8(sfm_handle h, const float* src, int64_t n_elems, uint8_t
  * cam_idx / pt_idx / uv may be host or device pointers; sfm_ba_create_problem copies them. */
 enum { SFM_CAMERA_SOLVER_AUTO = 0,       /* CG when n = n_cams * cam_dim <= 4096, else the factorisation (default) */
        SFM_CAMERA_SOLVER_CHOLESKY = 1,   /* bordered dense Cholesky + triangular solves */
-       SFM_CAMERA_SOLVER_CG = 2 };       /* conjugate gradients on the block-scaled system (n <= 4096), one launch per
-                                            iteration, relative residual 1e-13 (~25 iterations at 200 cameras, 2-3x faster
-                                            than the latency-bound factorisation); falls back to the factorisation when it
-                                            does not converge in 160 iterations or meets non-positive curvature */
+       SFM_CAMERA_SOLVER_CG = 2 };       /* conjugate gradients on the block-scaled system (n <= 4096), relative residual
+                                            1e-13 (~25 iterations at 200 cameras): ONE persistent launch per system for
+                                            n <= 2048 (the matrix rows in registers, the product all-gathered between
+                                            workgroups through self-validating 8-byte granules), one launch per iteration
+                                            above; falls back to the factorisation when it does not converge in 160
+                                            iterations or meets non-positive curvature */
 enum { SFM_BA_FP64 = 0,    /* every intermediate in float64 (default; the reference's arithmetic) */
        SFM_BA_MIXED = 1 }; /* Jacobian rows (and scaled residuals) stored in float32; every sum, W L^-T, S and the solve in float64 */
 typedef struct {
@@ -273,7 +275,10 @@ int sfm_ba_solve_pcg(sfm_handle h, sfm_ba_problem p, double alpha, int want_q, d
 int sfm_ba_step(sfm_handle h, sfm_ba_problem p, const double* x, double scale, double* x_new);
 int sfm_ba_finish_step(sfm_handle h, sfm_ba_problem p, const double* x, double scale, const double* x_new);
 
-/* Copy the SFM_SC_COUNT scalars to the host (synchronises the stream). */
+/* Copy the SFM_SC_COUNT scalars to the host (synchronises the stream).  This is also where a damped solve COMPLETES: the
+ * persistent conjugate-gradient launch of the second camera system (sfm_ba_finish_solve with want_q) is not waited for
+ * there - its verdict arrives with this synchronisation, and if it did not converge the q term is redone from the
+ * factorisation here (no exchange between ranks is involved).  Read the scalars through this call, not from the workspace. */
 int sfm_ba_read_scalars(sfm_handle h, sfm_ba_problem p, double* out_host);
 /* SFM_CAMERA_SOLVER_CG bookkeeping since the problem was created: CG iterations spent, solves that fell back. */
 int sfm_ba_solver_stats(sfm_ba_problem p, int64_t* cg_iters_host, int64_t* cg_fallbacks_host);

@@ -138,6 +138,14 @@ def load():
         if not os.path.exists(LIB_PATH):
             raise SfmError(f"{LIB_PATH} not built: run `python -m sfm_amd.build` "
                            "(hipcc --offload-arch=gfx950); there is no CPU fallback")
+        # PyTorch bundles its own HIP runtime (libamdhip64 under torch/lib, found through its RPATH).  Whichever copy is
+        # mapped first serves the whole process: if this library came first it would bind the system copy, torch would
+        # then bring its own, and the second runtime to initialise sees no device ("no ROCm-capable device is detected"
+        # from sfm_create).  So torch - the owner of device memory and streams here - goes first.
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         lib = C.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(lib, name)

@@ -369,22 +369,24 @@ __global__ __launch_bounds__(256) void k_cam_blocks_chunks(const int* __restrict
     typedef T pair_t __attribute__((ext_vector_type(2)));
     const int slot = tid >> 4, l16 = tid & 15;
     const bool live = l16 <= D;                              // pairs 0 .. D-1: Jc~, pair D: f~
-    for (int o0 = 0; o0 < cnt; o0 += 64) {
-      pair_t v[4];
+    // all 16 trips of a full chunk in flight: first the 16 observation ids, then the 16 row pieces
+    int kk[16];
 #pragma unroll
-      for (int it = 0; it < 4; ++it) {
-        const int o = o0 + it * 16 + slot;
-        v[it] = (pair_t)(T)0;
-        if (live && o < cnt) {
-          const int k = cam_obs[beg + o];
-          v[it] = l16 < D ? *(const pair_t*)(recA + (size_t)k * (2 * D) + 2 * l16) : *(const pair_t*)(recB + (size_t)k * 8 + 6);
-        }
-      }
+    for (int it = 0; it < 16; ++it) {
+      const int o = it * 16 + slot;
+      kk[it] = (live && o < cnt) ? cam_obs[beg + o] : -1;
+    }
+    pair_t v[16];
 #pragma unroll
-      for (int it = 0; it < 4; ++it) {
-        const int o = o0 + it * 16 + slot;
-        if (live && o < cnt) { s[o * LDW + 2 * l16] = (double)v[it].x; s[o * LDW + 2 * l16 + 1] = (double)v[it].y; }
-      }
+    for (int it = 0; it < 16; ++it) {
+      v[it] = (pair_t)(T)0;
+      if (kk[it] >= 0)
+        v[it] = l16 < D ? *(const pair_t*)(recA + (size_t)kk[it] * (2 * D) + 2 * l16) : *(const pair_t*)(recB + (size_t)kk[it] * 8 + 6);
+    }
+#pragma unroll
+    for (int it = 0; it < 16; ++it) {
+      const int o = it * 16 + slot;
+      if (kk[it] >= 0) { s[o * LDW + 2 * l16] = (double)v[it].x; s[o * LDW + 2 * l16 + 1] = (double)v[it].y; }
     }
   }
   __syncthreads();

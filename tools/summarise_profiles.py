@@ -5,11 +5,12 @@
   <round>_pmc_per_kernel.csv, <round>_pmc_summary.json                      HBM bytes per launch per kernel
   <round>_pmc_matcher.txt                                                   SQ counters of the matcher kernel
 gfx950: FETCH_SIZE tallies 128-byte requests at 64 bytes, so read bytes = 2 * FETCH_SIZE KiB * 1024
-(MI355X_MICROARCH.md).  usage: tools/summarise_profiles.py r02"""
+(MI355X_MICROARCH.md).    <round>_pmc_summary_coherent.json, <round>_l2_hits.json                   the same kernel on the spatially coherent scene; L2 hit counters
+usage: tools/summarise_profiles.py r03"""
 import collections, csv, glob, json, os, shutil, sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-rnd = sys.argv[1] if len(sys.argv) > 1 else "r02"
+rnd = sys.argv[1] if len(sys.argv) > 1 else "r03"
 # tools/collect_profiles.sh writes every collection into a time-stamped directory of its own and drops a `done` marker
 # last: take the NEWEST complete one (gpurun merges gpurun_out/ back, so older collections stay next to it)
 base = os.path.join(ROOT, "gpurun_out", "prof_" + rnd)
@@ -81,6 +82,32 @@ if rows:
         summary["k_axpy_step"]["note"] = f"calibration: reads 2 x {8 * (cams * d + 3 * pts) / 1e6:.2f} MB, writes 1 x"
     json.dump(summary, open(os.path.join(dst, f"{rnd}_pmc_summary.json"), "w"), indent=1)
     print(json.dumps({k: v for k, v in summary.items() if k.startswith("k_")}, indent=1))
+
+# the Schur gather on the spatially coherent scene (bench.py's ba_coherent_scene row reads this file)
+fe2, wr2 = counters(os.path.join(src, "fetch_coherent"), {"FETCH_SIZE"}), counters(os.path.join(src, "write_coherent"), {"WRITE_SIZE"})
+k2 = next((k for k in fe2 if k.startswith("k_schur_items")), None)
+if k2:
+    bench = json.load(open(os.path.join(src, "bench.json")))
+    wl = bench["config"]["workload"]
+    cams, pts, obs = int(wl.split(" cams")[0].split()[-1]), int(wl.split(" pts")[0].split()[-1]), int(wl.split(" obs")[0].split()[-1])
+    d = 10 if "cam block 10" in wl else 6
+    f = fe2[k2]["FETCH_SIZE"]; w = wr2.get(k2, {}).get("WRITE_SIZE", [0.0])
+    fm, wm = sum(f) / len(f), sum(w) / len(w)
+    json.dump({"provenance": "as <round>_pmc_summary.json, bench.py --visibility nearest (synth.make_scene(visibility='nearest'))",
+               "workload": {"cams": cams, "pts": pts, "obs": obs, "cam_dim": d, "visibility": "nearest"},
+               "k_schur_items": {"kernel": k2, "FETCH_SIZE_KiB": fm, "WRITE_SIZE_KiB": wm, "hbm_bytes_per_launch": int((2 * fm + wm) * 1024)}},
+              open(os.path.join(dst, f"{rnd}_pmc_summary_coherent.json"), "w"), indent=1)
+l2 = {}
+for tag, sub in (("random", "l2"), ("coherent", "l2_coherent")):
+    cs = counters(os.path.join(src, sub))
+    kk = next((k for k in cs if k.startswith("k_schur_items")), None)
+    if kk:
+        mean = {c: sum(v) / len(v) for c, v in cs[kk].items()}
+        mean["hit_rate"] = mean.get("TCC_HIT_sum", 0.0) / max(mean.get("TCC_REQ_sum", 1.0), 1.0)
+        l2[tag] = {"kernel": kk, **mean}
+if l2:
+    l2["note"] = "rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum, mean per launch of k_schur_items (128-byte line requests at the 8 L2s)"
+    json.dump(l2, open(os.path.join(dst, f"{rnd}_l2_hits.json"), "w"), indent=1)
 
 m = collections.defaultdict(list)
 for sub in ("msq1", "msq2"):
