@@ -237,6 +237,10 @@ int sfm_ba_cost(sfm_handle h, sfm_ba_problem p, const double* x);
  * intrinsics when cam_dim == 10 (the reprojection rows of `objective`, :478-486). */
 int sfm_ba_reproj_errors(sfm_handle h, sfm_ba_problem p, const double* x, int shared_k, double* err_out);
 
+/* sum over the problem's observations of ||proj - uv||^2 at x, to the host (synchronises): the reprojection part of the
+ * ||objective(x)||_2 that bundle_adjust logs before and after the solve (:522-524). */
+int sfm_ba_residual_norm2(sfm_handle h, sfm_ba_problem p, const double* x, int shared_k, double* out_host);
+
 /* The same without a problem object (nothing but the three packed arrays is needed): what
  * compute_reconstruction_stats (:582-631) computes per observation.  All pointers are device pointers; indices
  * must be in range (the caller's responsibility: there is no structure pass here). */

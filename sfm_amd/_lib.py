@@ -102,6 +102,7 @@ SIGNATURES = {
     "sfm_ba_run_trf": (C.c_int, [vp, vp, vp, C.POINTER(TRFOptions), REDUCE_FN, vp, C.POINTER(TRFResultC)]),
     "sfm_ba_cost": (C.c_int, [vp, vp, vp]),
     "sfm_ba_reproj_errors": (C.c_int, [vp, vp, vp, C.c_int, vp]),
+    "sfm_ba_residual_norm2": (C.c_int, [vp, vp, vp, C.c_int, C.POINTER(f64)]),
     "sfm_ba_linearize": (C.c_int, [vp, vp, vp]),
     "sfm_ba_finish_linearize": (C.c_int, [vp, vp]),
     "sfm_ba_schur_build": (C.c_int, [vp, vp, f64]),

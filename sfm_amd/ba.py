@@ -273,6 +273,13 @@ class GpuBA:
                     C.c_void_p(out.data_ptr()))
         return out
 
+    def residual_norm2(self, x=None, shared_k=False):
+        """sum ||proj - uv||^2 over this rank's observations at x (sfm_ba_residual_norm2), as a Python float."""
+        x = self.x if x is None else x
+        out = C.c_double(0.0)
+        self.h.call("sfm_ba_residual_norm2", self._pp, C.c_void_p(x.data_ptr()), 1 if shared_k else 0, C.byref(out))
+        return out.value
+
     def params(self):
         """(cams [C,d], pts [P,3]) of this rank as NumPy arrays."""
         x = self.x.cpu().numpy()

@@ -1232,6 +1232,34 @@ extern "C" int sfm_ba_reproj_errors(sfm_handle h, sfm_ba_problem p, const double
   return SFM_OK;
 }
 
+__global__ void k_sq_partials(int64_t n, const double* __restrict__ v, double* __restrict__ part);     // (defined with the loop's ||x|| helpers)
+
+// sum over this problem's observations of ||proj - uv||^2 at x, to the host: what bundle_adjust logs before and after the
+// solve (sfm_reconstruction.py:522-524 prints ||objective(x)||_2).  In the library so that the drop-in's write-back needs no
+// torch kernel: on a fresh box the first use of a torch elementwise / reduction kernel pages its code object in from disk,
+// ~0.1 s of the 0.15 s the round-2 driver run saw in `log_norms_and_write_back`.
+extern "C" int sfm_ba_residual_norm2(sfm_handle h, sfm_ba_problem p, const double* x, int shared_k, double* out_host) {
+  Lay L; int rc = check_problem(h, p, &L); if (rc) return rc;
+  if (!x || !out_host) return sfm_fail(h, SFM_ERR_ARG, "sfm_ba_residual_norm2", "null argument");
+  double* ws = (double*)p->workspace;
+  const int C = p->n_cams, D = p->cam_dim;
+  const int64_t N = p->n_obs;
+  DISPATCH_D(D, hipLaunchKernelGGL(k_campre<DD>, dim3(cdiv(C, 64)), dim3(64), 0, h->stream, x, C, p->fx0,
+                                   p->fy0, p->cx0, p->cy0, WS(L, campre2)));
+  if (shared_k)
+    hipLaunchKernelGGL(k_set_intrinsics, dim3(cdiv(C, 64)), dim3(64), 0, h->stream, C, p->fx0, p->fy0, p->cx0,
+                       p->cy0, WS(L, campre2));
+  hipLaunchKernelGGL(k_cost_obs, dim3((unsigned)L.nblk_obs), dim3(256), 0, h->stream, N, p->cam_idx,
+                     p->pt_idx, p->uv, x + (size_t)C * D, WS(L, campre2), (double*)nullptr, 0, 0, WS(L, tmp3));
+  hipLaunchKernelGGL(k_sq_partials, dim3((unsigned)L.nblk_obs), dim3(256), 0, h->stream, N, WS(L, tmp3), WS(L, part_obs));
+  hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(256), 0, h->stream, WS(L, part_obs), (int)L.nblk_obs, 1, WS(L, red_step) + 6);
+  SFM_HIP(h, hipMemcpyAsync(h->pinned + 48, WS(L, red_step) + 6, sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  SFM_HIP(h, hipStreamSynchronize(h->stream));
+  SFM_LAUNCH_CHECK(h, "sfm_ba_residual_norm2");
+  *out_host = h->pinned[48];
+  return SFM_OK;
+}
+
 extern "C" int sfm_reproj_errors(sfm_handle h, int32_t n_cams, int32_t cam_dim, int64_t n_obs, const int32_t* cam_idx,
                                  const int32_t* pt_idx, const double* uv, const double* x, double fx, double fy, double cx,
                                  double cy, int shared_k, double* err_out) {

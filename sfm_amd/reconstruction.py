@@ -164,7 +164,7 @@ class BundleAdjustMixin:
 
     def _residual_norm(self, be, x):
         """||objective(x)||_2 of the reference's closure: reprojection rows + regulariser rows."""
-        err2 = float((be.reproj_errors(x, shared_k=False) ** 2).sum().item())
+        err2 = be.residual_norm2(x, shared_k=False)          # summed inside the library: no torch kernel on this path
         if self.ba_cam_dim == 10:
             cams = x[:be.n].reshape(be.C, 10).cpu().numpy()
             p = be.desc
