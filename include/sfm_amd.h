@@ -36,6 +36,13 @@ const char* sfm_version(void);
 /* Stream-ordered copy of device memory the library owns (e.g. sfm_ba_get_structure) to the host; synchronises. */
 int         sfm_copy_to_host(sfm_handle h, void* dst_host, const void* src_device, int64_t bytes);
 
+/* The persistent conjugate-gradient kernel of the camera solve (SFM_CAMERA_SOLVER_CG, n <= 2048) needs its n / 8 workgroups
+ * co-resident.  A launch whose workgroups give up waiting for each other (bounded spins; e.g. the CUs are shared with another
+ * process) is abandoned, the solve falls back to one launch per iteration and the handle stops using the persistent kernel.
+ * sfm_cgs_persist_enable switches it back on (or off); sfm_cgs_persist_enabled reports the state. */
+int sfm_cgs_persist_enable(sfm_handle h, int enabled);
+int sfm_cgs_persist_enabled(sfm_handle h);
+
 /* Per-kernel device timing with HIP events recorded on the handle's stream (what bench.py's
  * roofline numbers are computed from).  Off by default.  sfm_profile_read synchronises the stream,
  * returns the accumulated milliseconds and launch count of one slot and resets it. */

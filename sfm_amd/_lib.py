@@ -68,6 +68,8 @@ SIGNATURES = {
     "sfm_set_stream": (C.c_int, [vp, vp]),
     "sfm_synchronize": (C.c_int, [vp]),
     "sfm_version": (C.c_char_p, []),
+    "sfm_cgs_persist_enable": (C.c_int, [vp, C.c_int]),
+    "sfm_cgs_persist_enabled": (C.c_int, [vp]),
     "sfm_set_profiling": (C.c_int, [vp, C.c_int]),
     "sfm_profile_read": (C.c_int, [vp, C.c_int, C.POINTER(f64), C.POINTER(i64)]),
     "sfm_match_workspace_bytes": (C.c_int, [C.c_int, i64, i64, C.c_int, C.POINTER(i64)]),

@@ -1677,7 +1677,10 @@ __global__ __launch_bounds__(256, 1) void k_cgs_persist(int n, double rtol2, int
                                                         const double* __restrict__ St, const double* __restrict__ rhs,
                                                         const double* __restrict__ x0 /* may be null: start from 0 */,
                                                         double* __restrict__ x_out, pr_u64* mail /* [2][n][2] granules */,
-                                                        pr_u64* abort_w, double* __restrict__ scal, PrFuse f) {
+                                                        pr_u64* abort_w, double* __restrict__ scal, PrFuse f, int sabotage) {
+  // test hook (SFM_CGS_SABOTAGE=1): workgroup 1 never publishes, as if it had not become resident - the others must run into
+  // their spin bound, post the abort word and leave; the host then takes the launch-per-iteration route
+  if (sabotage && blockIdx.x == 1) return;
   __shared__ double s_part[PR_ROWS][4];
   __shared__ double s_red[4];
   __shared__ int s_ok[4];
@@ -1895,8 +1898,8 @@ __global__ __launch_bounds__(256, 1) void k_cgs_persist(int n, double rtol2, int
 // synchronisation).  *ran = 0: the launch was abandoned - the caller takes the launch-per-iteration route (cgs_solve) with its
 // separate pre / post kernels; *status = 0: converged (and whatever `fuse` asked for has been done by workgroup 0).
 static bool cgs_persist_usable(sfm_ctx* h, int n) {
-  static const bool off = getenv("SFM_CGS_PERSIST") && getenv("SFM_CGS_PERSIST")[0] == '0';
-  return n <= PR_MAX_N && (n & 1) == 0 && !h->cgs_persist_off && !off;
+  const char* e = getenv("SFM_CGS_PERSIST");       // looked at per solve (a test switches it): "0" = one launch per iteration
+  return n <= PR_MAX_N && (n & 1) == 0 && !h->cgs_persist_off && !(e && e[0] == '0');
 }
 static int cgs_persist_launch(sfm_ctx* h, int n, int D, const double* St, const double* rhs, const double* x0_t, double* x_t, double* mail,
                               double* scal, double rtol, const PrFuse& fuse, int pin) {
@@ -1907,7 +1910,8 @@ static int cgs_persist_launch(sfm_ctx* h, int n, int D, const double* St, const 
   if (h->cgs_seq == 0u) h->cgs_seq = 1u;           // tag 0 is what zeroed memory reads as
   const unsigned salt = h->cgs_seq;
   const double rtol2 = rtol * rtol;
-#define PR_LAUNCH(NC, DD_) hipLaunchKernelGGL((k_cgs_persist<NC, DD_>), dim3(grid), dim3(256), 0, h->stream, n, rtol2, CGS_MAX_ITER, salt, St, rhs, x0_t, x_t, (pr_u64*)mail, abort_w, scal, fuse)
+  const int sabotage = (getenv("SFM_CGS_SABOTAGE") && getenv("SFM_CGS_SABOTAGE")[0] == '1' && grid > 1) ? 1 : 0;
+#define PR_LAUNCH(NC, DD_) hipLaunchKernelGGL((k_cgs_persist<NC, DD_>), dim3(grid), dim3(256), 0, h->stream, n, rtol2, CGS_MAX_ITER, salt, St, rhs, x0_t, x_t, (pr_u64*)mail, abort_w, scal, fuse, sabotage)
   if (D == 10) { if (nc <= 1) PR_LAUNCH(1, 10); else if (nc == 2) PR_LAUNCH(2, 10); else if (nc == 3) PR_LAUNCH(3, 10); else PR_LAUNCH(4, 10); }
   else { if (nc <= 1) PR_LAUNCH(1, 6); else if (nc == 2) PR_LAUNCH(2, 6); else if (nc == 3) PR_LAUNCH(3, 6); else PR_LAUNCH(4, 6); }
 #undef PR_LAUNCH

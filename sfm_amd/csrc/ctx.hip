@@ -106,6 +106,14 @@ extern "C" void sfm_destroy(sfm_handle h) {
   delete h;
 }
 
+extern "C" int sfm_cgs_persist_enable(sfm_handle h, int enabled) {
+  if (!h) return SFM_ERR_ARG;
+  h->cgs_persist_off = enabled ? 0 : 1;
+  return SFM_OK;
+}
+
+extern "C" int sfm_cgs_persist_enabled(sfm_handle h) { return h && !h->cgs_persist_off ? 1 : 0; }
+
 extern "C" const char* sfm_last_error(sfm_handle h) { return h ? h->err : "null handle"; }
 
 extern "C" int sfm_set_stream(sfm_handle h, void* hip_stream) {
