@@ -13,7 +13,7 @@
 // on the accumulators (k_knn2_u8) skips what cannot enter a top-2, the rest is ranked by ONE int32 key
 // = ((d^2 - QN_j) << 8) | row-in-window, i.e. v_lshl_add_u32 + v_min_i32 + v_med3_i32 per candidate; keys are unpacked
 // every 256 train rows.  Two distance kernels: k_knn2_u8 (train rows staged through LDS; batched image pairs, small
-// dims) and k_knn2_u8_direct (one pair with >= 12,288 queries: operands straight from L2, no LDS, no barrier).
+// dims) and k_knn2_u8_direct (one dim-128 pair of >= 8e6 distances: operands straight from L2, no LDS, no barrier).
 // Ranking rule = the reference's: OpenCV compares the float32 distances sqrtf(d^2), lowest train index first
 // on ties (matcher_oracle.py).  sqrtf is monotone and injective on integers below 2^22, so ranking on the integer
 // d^2 gives the same two neighbours whenever the second-best d^2 is below 2^22 (always, for SIFT descriptors:
@@ -937,7 +937,7 @@ static int match_launch(sfm_ctx* h, int metric, const void* q, int64_t nq_rows, 
   if (metric == SFM_METRIC_L2_U8) {
     const bool qb4 = qpw == 512;
     const char* d_env = getenv("SFM_MATCH_DIRECT");        // test / tuning knob: "0" = the LDS kernel also for the large case
-    // one pair at dim 128: the LDS-free kernel, with 4 query blocks per wave from 12,288 queries on and 2 below (8-20 % faster
+    // one pair at dim 128: the LDS-free kernel, with 4 query blocks per wave from 28,672 queries on and 2 below (8-20 % faster
     // than the LDS kernel at 2,000 .. 11,000 queries against 4,000 .. 50,000 train rows); the LDS kernel serves the batched
     // form, the smaller dims and the smallest pairs
     const bool direct2 = !wg && dim == 128 && !qb4 && (double)nq_rows * (double)nt_rows >= 8e6;      // below: launch-bound, the LDS kernel's lighter pre-pass wins by ~3 us

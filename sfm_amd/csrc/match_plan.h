@@ -53,7 +53,10 @@ static inline int64_t match_qpw(int metric, int dim, int64_t nq, bool batched) {
   // k_knn2_u8 with four query blocks per wave (512 queries per workgroup: half the train bytes through LDS per pair)
   // once there are enough queries to fill the chip that way; single segment, dim 128.  SFM_MATCH_QB = 2 / 4 overrides.
   const char* qb_env = getenv("SFM_MATCH_QB");
-  const bool qb4 = !batched && metric == SFM_METRIC_L2_U8 && dim == 128 && (qb_env ? qb_env[0] == '4' : nq >= 12288);     // measured crossover against the LDS kernel at 50,000 train rows: 10-12k queries
+  // measured crossover (round 3, 20 calls each, us per call, 4 blocks / 2 blocks per wave): 12,288 queries 82 / 74,
+  // 16,384: 98 / 89, 24,576: 166 / 146 (square sets; against 50,000 train rows 267 / 260), 32,768: 223 / 228 (301 / 317),
+  // 40,960: 312 / 332, 50,000: 418 / 451 - two blocks (three waves per SIMD) win up to ~28k queries
+  const bool qb4 = !batched && metric == SFM_METRIC_L2_U8 && dim == 128 && (qb_env ? qb_env[0] == '4' : nq >= 28672);
   return qb4 ? 512 : 256;
 }
 

@@ -140,43 +140,6 @@ __global__ __launch_bounds__(256) void k_xcd_fill(int C, const int* __restrict__
   for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) xcd_items[o + i] = f + i;
 }
 
-// key of an item for the order inside its block row (SFM_XCD_ORDER=krank): the position of its first observation k in its
-// camera's list - items of different blocks of a row that cover the same part of that list (the k side of the Schur gather)
-// then run next to each other in time and share the blocks in L2 while they are there
-__global__ __launch_bounds__(256) void k_item_keys(int n_items, const int* __restrict__ item_beg, const int* __restrict__ pair_k,
-                                                   const int* __restrict__ cam_idx, const int* __restrict__ cam_ptr,
-                                                   const int* __restrict__ cam_obs, int* __restrict__ key) {
-  const int it = blockIdx.x * 256 + threadIdx.x;
-  if (it >= n_items) return;
-  const int k = pair_k[item_beg[it]], c = cam_idx[k];
-  int lo = cam_ptr[c], hi = cam_ptr[c + 1];              // cam_obs is ascending inside a camera: lower bound of k
-  while (lo < hi) { const int mid = (lo + hi) >> 1; if (cam_obs[mid] < k) lo = mid + 1; else hi = mid; }
-  key[it] = lo - cam_ptr[c];
-}
-// xcd_items of row r = its items ordered by (key, item id): rank by counting, one workgroup per row (rows hold a few hundred
-// items; rows beyond ROW_SORT_MAX keep the plain order)
-constexpr int ROW_SORT_MAX = 4096;
-__global__ __launch_bounds__(256) void k_xcd_fill_sorted(int C, const int* __restrict__ row_first, const int* __restrict__ row_cnt,
-                                                         const int* __restrict__ row_base, const int* __restrict__ key,
-                                                         int* __restrict__ xcd_items) {
-  __shared__ int s_key[ROW_SORT_MAX];
-  const int r = blockIdx.x;
-  if (r >= C) return;
-  const int n = row_cnt[r], f = row_first[r], o = row_base[r];
-  if (n > ROW_SORT_MAX) {
-    for (int i = threadIdx.x; i < n; i += 256) xcd_items[o + i] = f + i;
-    return;
-  }
-  for (int i = threadIdx.x; i < n; i += 256) s_key[i] = key[f + i];
-  __syncthreads();
-  for (int i = threadIdx.x; i < n; i += 256) {
-    const int ki = s_key[i];
-    int pos = 0;
-    for (int j = 0; j < n; ++j) pos += (s_key[j] < ki || (s_key[j] == ki && j < i)) ? 1 : 0;
-    xcd_items[o + pos] = f + i;
-  }
-}
-
 int bits_for(uint64_t n_values) {       // bits needed to hold values 0 .. n_values - 1
   int b = 1;
   while (b < 32 && (1ull << b) < n_values) ++b;
@@ -381,18 +344,8 @@ extern "C" int sfm_ba_create_problem(sfm_handle h, const sfm_ba_desc* d, sfm_ba_
     for (int r = 0; r < C; ++r) { h_row_base[r] = run[grp[r]]; run[grp[r]] += h_row_cnt[r]; }
     PB_HIP(hipMemcpyAsync(p->xcd_ptr, xcd_ptr, 9 * 4, hipMemcpyHostToDevice, st));
     PB_HIP(hipMemcpyAsync(row_base, h_row_base.data(), (size_t)C * 4, hipMemcpyHostToDevice, st));
-    const char* oe = getenv("SFM_XCD_ORDER");
-    if (oe && oe[0] == 'k' && n_items > 0) {
-      DevBuf keys;
-      PB_HIP(keys.alloc((size_t)n_items * 4));
-      hipLaunchKernelGGL(k_item_keys, dim3(cdiv(n_items, 256)), dim3(256), 0, st, n_items, p->item_beg, p->pair_k, p->cam_idx, p->cam_ptr,
-                         p->cam_obs, keys.as<int>());
-      hipLaunchKernelGGL(k_xcd_fill_sorted, dim3(C), dim3(256), 0, st, C, row_first, row_cnt, row_base, keys.as<int>(), p->xcd_items);
-      PB_HIP(hipStreamSynchronize(st));     // keys goes out of scope; the host vectors above are pageable
-    } else {
-      hipLaunchKernelGGL(k_xcd_fill, dim3(4, C), dim3(256), 0, st, C, row_first, row_cnt, row_base, p->xcd_items);
-      PB_HIP(hipStreamSynchronize(st));     // the host vectors above are pageable: the copies must have left them
-    }
+    hipLaunchKernelGGL(k_xcd_fill, dim3(4, C), dim3(256), 0, st, C, row_first, row_cnt, row_base, p->xcd_items);
+    PB_HIP(hipStreamSynchronize(st));       // the host vectors above are pageable: the copies must have left them
   }
 
   // ---- camera chunks (<= 256 observations of one camera): C + 1 numbers, on the host

@@ -125,20 +125,7 @@ def build_structure(cam_idx, pt_idx, n_cams, n_pts):
     else:
         row_grp = np.arange(n_cams, dtype=np.int64) % 8
     item_grp = row_grp[item_row]
-    if os.environ.get("SFM_XCD_ORDER", "")[:1] == "k" and len(item_beg):
-        # inside a block row: items ordered by the position of their first observation in the camera's list (problem.hip,
-        # k_item_keys / k_xcd_fill_sorted), ties by item id; rows beyond 4096 items keep the plain order
-        k_first = (k[order])[item_beg]
-        cam_of = cam_idx[k_first]
-        pos_in_cam = np.empty(N, dtype=np.int64)
-        pos_in_cam[cam_obs] = np.arange(N, dtype=np.int64) - np.repeat(cam_ptr[:-1], np.diff(cam_ptr))
-        key = pos_in_cam[k_first]
-        big = np.bincount(item_row, minlength=n_cams)[item_row] > 4096
-        key = np.where(big, 0, key)
-        ids = np.arange(len(item_beg), dtype=np.int64)
-        xcd_items = np.lexsort((ids, key, item_row, item_grp))
-    else:
-        xcd_items = np.argsort(item_grp, kind="stable")
+    xcd_items = np.argsort(item_grp, kind="stable")
     xcd_ptr = np.zeros(9, dtype=np.int64)
     np.cumsum(np.bincount(item_grp, minlength=8), out=xcd_ptr[1:])
     return BAStructure(int(n_cams), int(n_pts), i32(cam_idx), i32(pt_idx), i32(pt_ptr), i32(cam_ptr),

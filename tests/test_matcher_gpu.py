@@ -196,17 +196,22 @@ def test_full_size_50k_all_rows(gpu_ready):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("qb", [None, "4", "2"])
 @pytest.mark.parametrize("nq,nt,kind", [(12288, 2049, "sift"), (16400, 1017, "uniform"), (20001, 3, "sift"),
-                                        (16390, 4101, "far"), (17000, 6000, "dups")])
-def test_l2_u8_many_queries_kernel_edges(gpu_ready, nq, nt, kind):
-    """From 12,288 queries on (dim 128, one pair) the distances come from the LDS-free kernel (k_knn2_u8_direct: train
-    set re-tiled into MFMA operand order, candidate filter, ranking pipelined across tiles).  Its edges against the C
+                                        (16390, 4101, "far"), (17000, 6000, "dups"), (28672, 300, "sift"), (29001, 2049, "uniform")])
+def test_l2_u8_many_queries_kernel_edges(gpu_ready, monkeypatch, nq, nt, kind, qb):
+    """One dim-128 pair with many queries: the distances come from the LDS-free kernel (k_knn2_u8_direct: train set
+    re-tiled into MFMA operand order, candidate filter, ranking pipelined across tiles) - with four query blocks per
+    wavefront from 28,672 queries on, two below (the planner's measured crossover; SFM_MATCH_QB forces either so that both
+    instantiations meet every edge).  Against the C
     oracle, every row: a query count that is not a multiple of the 512-query workgroup, train sets that end inside a
     32-row tile / a 256-row window / a split, three train rows only, rows far enough apart for the float32 re-ranking
     (d^2 >= 2^22), and many exact duplicates (ties on d^2: lowest train index first)."""
     import torch
     from oracle import ba_c
     from sfm_amd import synth, matcher
+    if qb is not None:
+        monkeypatch.setenv("SFM_MATCH_QB", qb)
     rng = np.random.default_rng(nq + nt)
     if kind == "sift":
         d1, d2 = synth.make_descriptors(nq, nt, seed=nq)
@@ -228,7 +233,7 @@ def test_l2_u8_many_queries_kernel_edges(gpu_ready, nq, nt, kind):
 
 def test_l2_u8_randomised_sizes_and_data(gpu_ready):
     """A fixed-seed sweep over both uint8 distance kernels and both filter settings (tools/stress_matcher.py runs the
-    long version): random query / train counts on either side of the kernel switch (12,288 queries) and of the filter
+    long version): random query / train counts on either side of the kernel switches (12,288 and 28,672 queries) and of the filter
     switch (2,048 train rows), SIFT-like, uniform and duplicate-heavy rows, every row against the C oracle."""
     import torch
     from oracle import ba_c
@@ -236,6 +241,8 @@ def test_l2_u8_randomised_sizes_and_data(gpu_ready):
     rng = np.random.default_rng(20260104)
     for case in range(10):
         nq = int(rng.integers(12288, 24000)) if case % 2 == 0 else int(rng.integers(1, 12288))
+        if case in (4, 8):
+            nq = int(rng.integers(28672, 33000))           # four query blocks per wavefront
         nt = int(rng.choice([rng.integers(2, 2048), rng.integers(2048, 12000)]))
         kind = case % 3
         if kind == 0:
