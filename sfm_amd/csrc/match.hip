@@ -141,8 +141,14 @@ typedef __attribute__((address_space(3))) void* lptr_t;
 #ifndef KNN_WAVES
 #define KNN_WAVES 2
 #endif
+// dim 256 (KS = 8: Hamming-256 / ORB over unpacked bits) holds twice the query and operand fragments and spills 7-15 registers
+// at two waves per SIMD.  Measured (round 3, 30,000 x 30,000 x 256 bits): one wave per SIMD, no spills (-DSFM_KNN_KS8_WAVES=1)
+// 535 us = 1.68e12 pairs/s; two waves with the spills 429 us = 2.10e12 - the second wave is worth more than the spills cost.
+#ifndef SFM_KNN_KS8_WAVES
+#define SFM_KNN_KS8_WAVES KNN_WAVES
+#endif
 template <int KS, int QB, bool FILTER>   // KS = dim / 32
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(KNN_WAVES, KNN_WAVES))) void k_knn2_u8(
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(KS == 8 ? SFM_KNN_KS8_WAVES : KNN_WAVES, KS == 8 ? SFM_KNN_KS8_WAVES : KNN_WAVES))) void k_knn2_u8(
     const uint8_t* __restrict__ q, int64_t nq, const uint8_t* __restrict__ tf, int64_t nt,
     const int* __restrict__ th_g, const int* __restrict__ par_g, const int* __restrict__ qn,
     int nsplit, int64_t rows_per_split, const MatchWG* __restrict__ wg, int64_t total_out, Cand* __restrict__ part, int* u2g) {
