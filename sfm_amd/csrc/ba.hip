@@ -1473,25 +1473,27 @@ __global__ __launch_bounds__(64) void k_diag_einv(int C, const double* __restric
     }
   if (bad) scal[CGS_FAIL] = 1.0;
 }
-// St[c][c2] = Einv_c (S[c][c2] + alpha [c == c2]) Einv_c2^T, both triangles.  One workgroup (128 threads, thread e < D*D owns
-// element e of a block) per block row c and SCALE_NB consecutive columns c2: a grid of one workgroup per block pair (40,000 at
-// 200 cameras) took 22 us for 32 MB of output - dispatch-bound.
+// St[c][c2] = Einv_c (S[c][c2] + alpha [c == c2]) Einv_c2^T.  One workgroup (128 threads, thread e < D*D owns element e of a
+// block) per block row c and SCALE_NB consecutive columns c2; only the blocks c2 >= c are computed, each is written twice
+// (St is symmetric: the block and its transpose).  All blocks of a workgroup move through each stage together: three
+// barriers per workgroup, not per block.  (One workgroup per block pair, 40,000 at 200 cameras: 22 us, dispatch-bound.)
 constexpr int SCALE_NB = 8;
 template <int D>
 __global__ __launch_bounds__(128) void k_scale_system(int n, int C, const double* __restrict__ S, double alpha,
                                                       const double* __restrict__ Einv, double* __restrict__ St) {
-  // all SCALE_NB blocks of the workgroup move through each stage together: three barriers per workgroup, not per block
   __shared__ double sB[SCALE_NB][D * D], sT[SCALE_NB][D * D], sE2[SCALE_NB][D * D], sE1[D * D];
   const int c = blockIdx.x, e = threadIdx.x;
   const int a = e / D, b = e - a * D;
   const int c2_0 = blockIdx.y * SCALE_NB;
+  if (c2_0 + SCALE_NB <= c) return;                      // (workgroup-uniform) nothing at or right of the diagonal here
   const int nb = (C - c2_0) < SCALE_NB ? (C - c2_0) : SCALE_NB;
   if (e < D * D) {
     sE1[e] = Einv[(size_t)c * D * D + e];
 #pragma unroll
     for (int j = 0; j < SCALE_NB; ++j)
-      if (j < nb) {
-        // only the lower triangle of S is read: it is the part the multi-rank exchange carries (sfm_ba_pack_system)
+      if (j < nb && c2_0 + j >= c) {
+        // block (c, c2 >= c) of S from its LOWER triangle - the part the multi-rank exchange carries (sfm_ba_pack_system):
+        // S[c][c2][a][b] = S[c2 D + b][c D + a]
         const int c2 = c2_0 + j, row = c * D + a, col = c2 * D + b;
         sB[j][e] = (col <= row ? S[(size_t)row * n + col] : S[(size_t)col * n + row]) + ((c == c2 && a == b) ? alpha : 0.0);
         sE2[j][e] = Einv[(size_t)c2 * D * D + e];
@@ -1501,7 +1503,7 @@ __global__ __launch_bounds__(128) void k_scale_system(int n, int C, const double
   if (e < D * D) {
 #pragma unroll
     for (int j = 0; j < SCALE_NB; ++j)
-      if (j < nb) {
+      if (j < nb && c2_0 + j >= c) {
         double t = 0.0;
 #pragma unroll
         for (int k = 0; k < D; ++k) t += sE1[a * D + k] * sB[j][k * D + b];    // Einv_c is lower: entries k > a are stored zeros
@@ -1512,11 +1514,13 @@ __global__ __launch_bounds__(128) void k_scale_system(int n, int C, const double
   if (e < D * D) {
 #pragma unroll
     for (int j = 0; j < SCALE_NB; ++j)
-      if (j < nb) {
+      if (j < nb && c2_0 + j >= c) {
         double t = 0.0;
 #pragma unroll
         for (int k = 0; k < D; ++k) t += sT[j][a * D + k] * sE2[j][b * D + k];
-        St[(size_t)(c * D + a) * n + (c2_0 + j) * D + b] = t;
+        const int c2 = c2_0 + j;
+        St[(size_t)(c * D + a) * n + c2 * D + b] = t;
+        if (c2 != c) St[(size_t)(c2 * D + b) * n + c * D + a] = t;
       }
   }
 }

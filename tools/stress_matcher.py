@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Randomised parity sweep of the uint8 kNN kernels against the C oracle (every row): sizes across the kernel switch
-(12,288 queries), the filter switch (2,048 train rows), ragged tiles / windows / splits, SIFT-like, uniform, duplicate-heavy
+(12,288 and 28,672 queries), the filter switch (2,048 train rows), ragged tiles / windows / splits, SIFT-like, uniform, duplicate-heavy
 and far-apart (float32 re-ranking) data, single pairs and batched segments.  Prints one line per case; exits 1 on a mismatch."""
 import os, sys, time
 import numpy as np
