@@ -1780,7 +1780,7 @@ __global__ __launch_bounds__(256, 1) void k_cgs_persist(int n, double rtol2, int
       }
       if (__all(all)) { ok = true; break; }
       if ((spins & 31u) == 31u && __hip_atomic_load(abort_w, PR_RLX_AGENT) == (pr_u64)salt) break;     // somebody gave up
-      if (sabotage >= 0) __builtin_amdgcn_s_sleep(2);   // sabotage < 0: experiment, no sleep between passes
+      __builtin_amdgcn_s_sleep(2);                    // (polling without the sleep measured the same: 135.1 / 100.1 us per system)
     }
     if (lane == 0) s_ok[w] = ok ? 1 : 0;
     __syncthreads();
@@ -1914,8 +1914,7 @@ static int cgs_persist_launch(sfm_ctx* h, int n, int D, const double* St, const 
   if (h->cgs_seq == 0u) h->cgs_seq = 1u;           // tag 0 is what zeroed memory reads as
   const unsigned salt = h->cgs_seq;
   const double rtol2 = rtol * rtol;
-  int sabotage = (getenv("SFM_CGS_SABOTAGE") && getenv("SFM_CGS_SABOTAGE")[0] == '1' && grid > 1) ? 1 : 0;
-  if (!sabotage && getenv("SFM_CGS_NOSLEEP") && getenv("SFM_CGS_NOSLEEP")[0] == '1') sabotage = -1;      // experiment: poll without s_sleep
+  const int sabotage = (getenv("SFM_CGS_SABOTAGE") && getenv("SFM_CGS_SABOTAGE")[0] == '1' && grid > 1) ? 1 : 0;
 #define PR_LAUNCH(NC, DD_) hipLaunchKernelGGL((k_cgs_persist<NC, DD_>), dim3(grid), dim3(256), 0, h->stream, n, rtol2, CGS_MAX_ITER, salt, St, rhs, x0_t, x_t, (pr_u64*)mail, abort_w, scal, fuse, sabotage)
   if (D == 10) { if (nc <= 1) PR_LAUNCH(1, 10); else if (nc == 2) PR_LAUNCH(2, 10); else if (nc == 3) PR_LAUNCH(3, 10); else PR_LAUNCH(4, 10); }
   else { if (nc <= 1) PR_LAUNCH(1, 6); else if (nc == 2) PR_LAUNCH(2, 6); else if (nc == 3) PR_LAUNCH(3, 6); else PR_LAUNCH(4, 6); }
