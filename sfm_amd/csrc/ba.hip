@@ -640,8 +640,18 @@ __global__ __launch_bounds__(256) void k_build_G(int64_t N, const int* __restric
 // row = (l>>4) + 4*reg.  Pair ids are loaded 64 at a time (coalesced) and broadcast with v_readlane so the
 // 16 gathers of 8 pairs are in flight together.  k_schur_assemble then sums the items of each block in
 // order (bitwise reproducible), adds B_c on the diagonal and writes the block and its mirror.
+// build-time tuning knobs of the gather: waves per SIMD the register budget is cut for, and 16-byte chunk loads in flight per
+// operand and wave.  Measured (round 3, tools/exp_schur_occupancy.sh; us per launch d = 10 / d = 6): (5 waves, 8 loads) 312 / 349,
+// (6, 6) 312 / 325, (7, 5) 307 / 313, (8, 4) 306 / 309, (8, 3) 306 / 309, (8, 2) 307 / 308: the same bytes in flight spread over
+// more waves hide the LDS / MFMA phases of each other; both block sizes then sit at the two-lines-per-block traffic floor.
+#ifndef SFM_SCHUR_WAVES
+#define SFM_SCHUR_WAVES 8
+#endif
+#ifndef SFM_SCHUR_U
+#define SFM_SCHUR_U 4
+#endif
 template <int D, typename T, int GS, bool KPACK, bool NTK2>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) void k_schur_items(const int* __restrict__ xcd_ptr, const int* __restrict__ xcd_items,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SFM_SCHUR_WAVES, SFM_SCHUR_WAVES))) void k_schur_items(const int* __restrict__ xcd_ptr, const int* __restrict__ xcd_items,
                                                      const int* __restrict__ item_beg,
                                                      const int* __restrict__ item_end,
                                                      const int* __restrict__ pair_k, const int* __restrict__ pair_k2,
@@ -668,7 +678,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) voi
   static_assert(D < 16, "column D of the 16 x 16 product is the right-hand side");
   constexpr int CH = BB / 16;                  // 16-byte chunks per block
   constexpr int BPL = 64 / CH;                 // blocks per load instruction
-  constexpr int U = (64 + BPL - 1) / BPL < 8 ? (64 + BPL - 1) / BPL : 8;   // load instructions in flight per operand (16 costs occupancy: measured slower)
+  constexpr int U = (64 + BPL - 1) / BPL < SFM_SCHUR_U ? (64 + BPL - 1) / BPL : SFM_SCHUR_U;   // load instructions in flight per operand
   constexpr int PB = U * BPL;                  // pairs per batch
   __shared__ __attribute__((aligned(16))) char s_stage[4][2][BPL * BB];
   __shared__ double s_e[4][64][3];             // diagonal items: e_j of the 64 pairs whose ids the wave holds
