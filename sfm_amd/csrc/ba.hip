@@ -641,17 +641,41 @@ __global__ __launch_bounds__(256) void k_build_G(int64_t N, const int* __restric
 // 16 gathers of 8 pairs are in flight together.  k_schur_assemble then sums the items of each block in
 // order (bitwise reproducible), adds B_c on the diagonal and writes the block and its mirror.
 // build-time tuning knobs of the gather: waves per SIMD the register budget is cut for, and 16-byte chunk loads in flight per
-// operand and wave.  Measured (round 3, tools/exp_schur_occupancy.sh; us per launch d = 10 / d = 6): (5 waves, 8 loads) 312 / 349,
-// (6, 6) 312 / 325, (7, 5) 307 / 313, (8, 4) 306 / 309, (8, 3) 306 / 309, (8, 2) 307 / 308: the same bytes in flight spread over
-// more waves hide the LDS / MFMA phases of each other; both block sizes then sit at the two-lines-per-block traffic floor.
-#ifndef SFM_SCHUR_WAVES
-#define SFM_SCHUR_WAVES 8
+// operand and wave.  Measured (round 3, tools/exp_schur_occupancy.sh, tools/exp_coherent_occupancy.sh; us per launch):
+//   (waves, loads)     d = 10 random   d = 6 random   d = 10 coherent scene
+//   (5, 8)                  312             349              335
+//   (6, 6)                  312             325              342
+//   (7, 5)                  307             313              346
+//   (8, 4)                  306             309              351
+// More waves hide the LDS / MFMA phases of each other - decisive for d = 6, whose 7-block slabs and 63 loader lanes leave
+// more of those - but they also widen the set of lines in flight per XCD and cost L2 hits on the k side (31 % -> 28 % of the
+// line requests on the random scene, 19 % -> 14 % on the coherent one).  Shipped: (5, 8) for d = 10, (8, 4) for d = 6.
+#ifndef SFM_SCHUR_WAVES_D10
+#define SFM_SCHUR_WAVES_D10 5
 #endif
-#ifndef SFM_SCHUR_U
-#define SFM_SCHUR_U 4
+#ifndef SFM_SCHUR_U_D10
+#define SFM_SCHUR_U_D10 8
+#endif
+#ifndef SFM_SCHUR_WAVES_D6
+#define SFM_SCHUR_WAVES_D6 8
+#endif
+#ifndef SFM_SCHUR_U_D6
+#define SFM_SCHUR_U_D6 4
+#endif
+#ifdef SFM_SCHUR_WAVES          /* one setting for both block sizes (the experiment scripts) */
+#undef SFM_SCHUR_WAVES_D10
+#undef SFM_SCHUR_WAVES_D6
+#define SFM_SCHUR_WAVES_D10 SFM_SCHUR_WAVES
+#define SFM_SCHUR_WAVES_D6 SFM_SCHUR_WAVES
+#endif
+#ifdef SFM_SCHUR_U
+#undef SFM_SCHUR_U_D10
+#undef SFM_SCHUR_U_D6
+#define SFM_SCHUR_U_D10 SFM_SCHUR_U
+#define SFM_SCHUR_U_D6 SFM_SCHUR_U
 #endif
 template <int D, typename T, int GS, bool KPACK, bool NTK2>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SFM_SCHUR_WAVES, SFM_SCHUR_WAVES))) void k_schur_items(const int* __restrict__ xcd_ptr, const int* __restrict__ xcd_items,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(D == 6 ? SFM_SCHUR_WAVES_D6 : SFM_SCHUR_WAVES_D10, D == 6 ? SFM_SCHUR_WAVES_D6 : SFM_SCHUR_WAVES_D10))) void k_schur_items(const int* __restrict__ xcd_ptr, const int* __restrict__ xcd_items,
                                                      const int* __restrict__ item_beg,
                                                      const int* __restrict__ item_end,
                                                      const int* __restrict__ pair_k, const int* __restrict__ pair_k2,
@@ -678,7 +702,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SFM_SCHUR_W
   static_assert(D < 16, "column D of the 16 x 16 product is the right-hand side");
   constexpr int CH = BB / 16;                  // 16-byte chunks per block
   constexpr int BPL = 64 / CH;                 // blocks per load instruction
-  constexpr int U = (64 + BPL - 1) / BPL < SFM_SCHUR_U ? (64 + BPL - 1) / BPL : SFM_SCHUR_U;   // load instructions in flight per operand
+  constexpr int UMAX = D == 6 ? SFM_SCHUR_U_D6 : SFM_SCHUR_U_D10;
+  constexpr int U = (64 + BPL - 1) / BPL < UMAX ? (64 + BPL - 1) / BPL : UMAX;   // load instructions in flight per operand
   constexpr int PB = U * BPL;                  // pairs per batch
   __shared__ __attribute__((aligned(16))) char s_stage[4][2][BPL * BB];
   __shared__ double s_e[4][64][3];             // diagonal items: e_j of the 64 pairs whose ids the wave holds
