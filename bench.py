@@ -252,7 +252,8 @@ def main():
         return r
 
     bytes_per_obs = 8 + 16 + 16 + 2 * d * 8 + 48
-    cg_on = args.camera_solver != "cholesky" and n_sys <= 4096
+    big_cg = n_sys > 4096 and os.environ.get("SFM_CGS_BIG", "1") != "0"
+    cg_on = args.camera_solver != "cholesky" and (n_sys <= 4096 or big_cg)
     cam_roofs = []
     if cg_on and "chol" in kernels:
         # both slots of the camera solve hold CG solves here (chol: the step system incl. its scaling kernels, trsv: the system
@@ -262,10 +263,20 @@ def main():
         n_systems = kernels["chol"]["launches"] + kernels.get("trsv", {}).get("launches", 0)
         per_system = its / max(n_systems, 1)
         persistent = n_sys <= 2048 and os.environ.get("SFM_CGS_PERSIST", "1") != "0"
-        r = roof(("k_cgs_persist" if persistent else "k_cgs_iter") + ": CG on the block-scaled camera system, n = %d" % n_sys, "hbm",
-                 (1.0 if persistent else per_system) * n_sys * n_sys * 8.0, 1e9, HBM_PEAK_GBS, "GB/s", "trsv" if "trsv" in kernels else "chol",
+        # n > 4096: every iteration streams the 128 x 128 tiles of the LOWER triangle of S~ (diagonal tiles whole) from HBM
+        nb_t = (n_sys + 127) // 128
+        edge = n_sys - (nb_t - 1) * 128
+        tri_bytes = 8.0 * sum((edge if I == nb_t - 1 else 128) * (edge if J == nb_t - 1 else 128) for I in range(nb_t) for J in range(I + 1))
+        r = roof(("k_cgs_big_symv" if big_cg else "k_cgs_persist" if persistent else "k_cgs_iter") +
+                 ": CG on the block-scaled camera system, n = %d" % n_sys, "hbm",
+                 per_system * tri_bytes if big_cg else (1.0 if persistent else per_system) * n_sys * n_sys * 8.0, 1e9, HBM_PEAK_GBS, "GB/s",
+                 "trsv" if "trsv" in kernels else "chol",
                  note="%.1f iterations per system on average (relative residual 1e-13); %d fallbacks to the factorisation.  "
-                      % (per_system, fb) + ("Exchange-latency bound, not bandwidth bound: one launch per system, S~ (n^2 doubles) is read "
+                      % (per_system, fb) + ("three launches per iteration: k_cgs_big_symv streams the lower triangle of S~ once (%.0f MB: "
+                      "every 128 x 128 tile serves both products it takes part in), k_cgs_big_reduce adds the per-tile partial sums in fixed "
+                      "order, k_cgs_big_update runs the recurrences; `achieved` prices the triangle's bytes over the whole slot of the "
+                      "second system (prologue + all three kernels + host looks)" % (tri_bytes / 1e6) if big_cg else
+                      "Exchange-latency bound, not bandwidth bound: one launch per system, S~ (n^2 doubles) is read "
                       "once into registers, every iteration all-gathers the n entries of S~ p between the n / 8 workgroups through 8-byte "
                       "granules; `achieved` prices that single read of S~ against HBM and is small by construction - see us_per_iteration "
                       "(slot of the second system: prologue + iterations + epilogue)" if persistent else
@@ -329,8 +340,8 @@ def main():
         ba_mixed["kernels_us"] = {k: round(v[0] / v[1] * 1e3, 2) for k, v in rm["prof"].items() if v[1] > 0}
 
     ba_alt = None
-    if not args.no_alt_camera_solver and n_sys <= 4096:
-        other = "cg" if args.camera_solver == "cholesky" else "cholesky"       # auto = cg at this size
+    if not args.no_alt_camera_solver and (n_sys <= 4096 or big_cg):
+        other = "cg" if args.camera_solver == "cholesky" else "cholesky"       # auto = cg
         ra = fixed_schedule_run(d, "fp64", True, camera_solver=other)
         ba_alt = brief(ra, f"same scene and schedule, formed camera system solved by {other} instead of {args.camera_solver}")
         ba_alt["camera_solver"] = other

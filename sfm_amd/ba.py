@@ -34,8 +34,9 @@ class GpuBA:
     solver="pcg" solves it by preconditioned conjugate gradients on the implicit Schur complement
     (sfm_ba_solve_pcg): no n x n matrix, one n-vector exchanged per iteration between ranks.
     camera_solver (solver="dense" only): how the formed system is solved - "auto" (default): conjugate gradients on
-    the block-scaled system when n <= 4096 (one launch per iteration, Cholesky fallback), else the bordered
-    Cholesky; "cholesky" / "cg" force one.
+    the block-scaled system (n <= 2048: one persistent launch per system; up to 4096: one launch per iteration; beyond:
+    tile-streaming over the symmetric half of the matrix), with the bordered Cholesky as fallback; "cholesky" / "cg"
+    force one.
     """
 
     def __init__(self, cams, pts, cam_idx, pt_idx, uv, K0, width=1024.0, height=768.0,

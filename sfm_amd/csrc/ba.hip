@@ -1482,6 +1482,7 @@ __global__ void k_finish_solve_pcg(int n, const double* __restrict__ pc, const d
 // direction of non-positive curvature, the caller falls back to the Cholesky route: S itself is left untouched.
 constexpr int CGS_MAX_N = 4096;          // the direction vector lives in LDS (32 KB); larger systems use the factorisation
 constexpr int CGS_MAX_ITER = 160;
+constexpr int CGS_BIG_MAX_ITER = 400;   // the tile-streaming route for n > CGS_MAX_N (cgs_solve_big)
 constexpr double CGS_RTOL = 1e-13;       // ||r|| <= CGS_RTOL ||r_0|| on the scaled system
 enum { CGS_RR0 = 0, CGS_RR = 1, CGS_ITER = 2, CGS_FAIL = 3, CGS_DONE = 4,
        CGS_RR_SLOT = 5 };   // [5], [6]: ||r||^2 handed from launch to launch; launch `it` reads slot (it + 1) & 1, writes slot it & 1
@@ -2016,6 +2017,197 @@ static int cgs_solve(sfm_ctx* h, int n, const double* St, const double* rhs_t, d
   return SFM_OK;
 }
 
+// ------------------------------------------------------------------------------------ the same CG for large systems
+// n > CGS_MAX_N (1000 cameras: n = 10,000, S~ = 800 MB).  Nothing of S~ stays in a cache between iterations, so an iteration is
+// a stream over the matrix and what counts is how many bytes of it are read: S~ is symmetric, and a 128 x 128 tile (I, J),
+// J < I, of its lower triangle serves BOTH products it takes part in - rows I of S~ p get A_IJ p_J, rows J get A_IJ^T p_I -
+// so an iteration reads n^2 / 2 entries (414 MB at n = 10,000 against 800 MB; the factorisation it replaces: 14 ms per damped
+// solve, ~50 iterations of this per system).  One workgroup per tile (3,160 at n = 10,000); wave w owns 32 of its rows, a lane
+// two of its columns (one 16-byte load per row and lane: a row of the tile is one contiguous KiB).  The column sums stay in
+// the lane (two accumulators over the wave's rows, the four waves added in fixed order through LDS); the row sums of 16 rows
+// at a time are reduced over the 64 lanes by a halving exchange (lane_rows16_sum: 15 + 2 shuffles instead of 16 x 6).  Every
+// tile writes its partial sums to a slot of its own, P[k][i] with k = J for the row sums of (I, J) and k = I for its column
+// sums - each (k, i) is written exactly once per iteration - and k_cgs_big_reduce adds the nb = ceil(n / 128) slots of an
+// entry in fixed order: no atomics, bitwise reproducible.  The recurrences run in ONE workgroup (k_cgs_big_update: 5 vectors
+// of n doubles, ~6 us); three launches per iteration, ~15 us of them around the ~75 us stream.  State in the factor's
+// transposed-copy buffer (free on this route): r | p | S~p | dots[nb] | P[nb][n].
+constexpr int SY_T = 128;
+
+// v[q] = this lane's part of the sum of row q; returns (in every lane) the sum over the 64 lanes of row (lane >> 2)
+__device__ __forceinline__ double lane_rows16_sum(double (&v)[16], int lane) {
+  {
+    const bool hi = (lane & 32) != 0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const double send = hi ? v[k] : v[k + 8], keep = hi ? v[k + 8] : v[k];
+      v[k] = keep + __shfl_xor(send, 32, 64);
+    }
+  }
+  {
+    const bool hi = (lane & 16) != 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const double send = hi ? v[k] : v[k + 4], keep = hi ? v[k + 4] : v[k];
+      v[k] = keep + __shfl_xor(send, 16, 64);
+    }
+  }
+  {
+    const bool hi = (lane & 8) != 0;
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const double send = hi ? v[k] : v[k + 2], keep = hi ? v[k + 2] : v[k];
+      v[k] = keep + __shfl_xor(send, 8, 64);
+    }
+  }
+  double t;
+  {
+    const bool hi = (lane & 4) != 0;
+    const double send = hi ? v[0] : v[1], keep = hi ? v[1] : v[0];
+    t = keep + __shfl_xor(send, 4, 64);
+  }
+  t += __shfl_xor(t, 2, 64);
+  t += __shfl_xor(t, 1, 64);
+  return t;
+}
+
+// P[J][rows of I] = A_IJ p_J and (J < I) P[I][rows of J] = A_IJ^T p_I for tile t = blockIdx.x of the lower triangle
+__global__ __launch_bounds__(256) void k_cgs_big_symv(int n, const double* __restrict__ St, const double* __restrict__ pvec,
+                                                      double* __restrict__ P, const double* __restrict__ scal) {
+  if (scal[CGS_DONE] != 0.0) return;                // converged (or broken) in an earlier launch of this batch
+  __shared__ double s_pI[SY_T];
+  __shared__ double s_col[4][SY_T];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  // t -> (I, J), J <= I: I = floor((sqrt(8 t + 1) - 1) / 2), corrected for the rounding of the root
+  const int t = (int)blockIdx.x;
+  int I = (int)((sqrt(8.0 * (double)t + 1.0) - 1.0) * 0.5);
+  while ((I + 1) * (I + 2) / 2 <= t) ++I;
+  while (I * (I + 1) / 2 > t) --I;
+  const int J = t - I * (I + 1) / 2;
+  const int r0 = I * SY_T, c0 = J * SY_T;
+  const int jc = c0 + 2 * lane;                     // n is even: jc < n implies jc + 1 < n
+  const bool col_ok = jc < n;
+  double2 a[2][16];
+#pragma unroll
+  for (int b = 0; b < 2; ++b)
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      const int row = r0 + w * 32 + b * 16 + q;
+      a[b][q] = (col_ok && row < n) ? *(const double2*)(St + (size_t)row * n + jc) : make_double2(0.0, 0.0);
+    }
+  const double pj0 = col_ok ? pvec[jc] : 0.0, pj1 = col_ok ? pvec[jc + 1] : 0.0;
+  if (tid < SY_T) s_pI[tid] = (r0 + tid < n) ? pvec[r0 + tid] : 0.0;
+  __syncthreads();
+  double cs0 = 0.0, cs1 = 0.0;
+#pragma unroll
+  for (int b = 0; b < 2; ++b) {
+    double v[16];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      const double pi = s_pI[w * 32 + b * 16 + q];
+      v[q] = a[b][q].x * pj0 + a[b][q].y * pj1;
+      cs0 += a[b][q].x * pi; cs1 += a[b][q].y * pi;
+    }
+    const double rs = lane_rows16_sum(v, lane);
+    const int row = r0 + w * 32 + b * 16 + (lane >> 2);
+    if ((lane & 3) == 0 && row < n) P[(size_t)J * n + row] = rs;
+  }
+  if (I != J) {                                      // (workgroup-uniform) the diagonal tile is stored whole: row sums only
+    s_col[w][2 * lane] = cs0; s_col[w][2 * lane + 1] = cs1;
+    __syncthreads();
+    if (tid < SY_T && c0 + tid < n) P[(size_t)I * n + c0 + tid] = (s_col[0][tid] + s_col[1][tid]) + (s_col[2][tid] + s_col[3][tid]);
+  }
+}
+// S~p = sum over the nb slots (fixed order); dots[B] = the block's part of p . S~p.  One workgroup of 128 per block of 128 entries.
+__global__ __launch_bounds__(128) void k_cgs_big_reduce(int n, int nb, const double* __restrict__ P, const double* __restrict__ pvec,
+                                                        double* __restrict__ Ap, double* __restrict__ dots, const double* __restrict__ scal) {
+  if (scal[CGS_DONE] != 0.0) return;
+  __shared__ double s_w[2];
+  const int i = (int)blockIdx.x * SY_T + threadIdx.x;
+  double s = 0.0;
+  if (i < n) {
+#pragma unroll 8
+    for (int k = 0; k < nb; ++k) s += P[(size_t)k * n + i];
+    Ap[i] = s;
+  }
+  double d = wave_sum(i < n ? s * pvec[i] : 0.0);
+  if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = d;
+  __syncthreads();
+  if (threadIdx.x == 0) dots[blockIdx.x] = s_w[0] + s_w[1];
+}
+__device__ __forceinline__ double block_sum1024(double v, double* s);
+// alpha = rr / p.S~p;  x += alpha p;  r -= alpha S~p;  beta = rr' / rr;  p = r + beta p.  ONE workgroup.
+__global__ __launch_bounds__(1024) void k_cgs_big_update(int n, int nb, int it, double rtol2, double* __restrict__ r, double* __restrict__ pvec,
+                                                         const double* __restrict__ Ap, const double* __restrict__ dots,
+                                                         double* __restrict__ x, double* __restrict__ scal) {
+  __shared__ double s_red[17];
+  const int tid = threadIdx.x;
+  const bool stop = scal[CGS_DONE] != 0.0;
+  const double rr_old = scal[CGS_RR], rr0 = scal[CGS_RR0];
+  double d = 0.0;
+  for (int b = tid; b < nb; b += 1024) d += dots[b];
+  const double pAp = block_sum1024(d, s_red);       // (its barriers also order the reads above before the writes below)
+  if (stop) return;
+  if (!(pAp > 0.0)) {                                // non-positive curvature (or NaN): S~ is not positive definite
+    if (tid == 0) { scal[CGS_FAIL] = 2.0; scal[CGS_DONE] = 1.0; }
+    return;
+  }
+  const double al = rr_old / pAp;
+  double rr = 0.0;
+  for (int i = tid; i < n; i += 1024) {
+    x[i] += al * pvec[i];
+    const double rn = r[i] - al * Ap[i];
+    r[i] = rn; rr += rn * rn;
+  }
+  const double rr_new = block_sum1024(rr, s_red);
+  const double beta = rr_new / rr_old;
+  for (int i = tid; i < n; i += 1024) pvec[i] = r[i] + beta * pvec[i];
+  if (tid == 0) {
+    scal[CGS_RR] = rr_new; scal[CGS_ITER] = (double)(it + 1);
+    if (rr_new <= rtol2 * rr0) scal[CGS_DONE] = 1.0;
+  }
+}
+
+// SFM_CGS_BIG=0: systems beyond CGS_MAX_N take the factorisation as before round 3 (looked at per solve: a test switches it)
+static bool cgs_big_allowed(int n) {
+  if (n <= CGS_MAX_N) return true;
+  const char* e = getenv("SFM_CGS_BIG");
+  return !(e && e[0] == '0');
+}
+static int cgs_solve_big(sfm_ctx* h, int n, const double* St, const double* rhs_t, double* x_t, double* buf, double* scal,
+                         double rtol, int* iters_out, int* status) {
+  const double rtol2 = rtol * rtol;
+  *status = 1;
+  const int nb = (int)cdiv(n, SY_T);
+  const unsigned n_tiles = (unsigned)((int64_t)nb * (nb + 1) / 2);
+  double *r = buf, *pv = buf + n, *Ap = buf + 2 * (size_t)n, *dots = buf + 3 * (size_t)n, *P = dots + ((nb + 127) & ~127);
+  hipLaunchKernelGGL(k_cgs_init, dim3(1), dim3(256), 0, h->stream, n, rhs_t, x_t, r, pv, scal);
+  int it = 0;
+  int batch = 24;
+  while (it < CGS_BIG_MAX_ITER) {
+    for (int b = 0; b < batch && it < CGS_BIG_MAX_ITER; ++b, ++it) {
+      hipLaunchKernelGGL(k_cgs_big_symv, dim3(n_tiles), dim3(256), 0, h->stream, n, St, pv, P, scal);
+      hipLaunchKernelGGL(k_cgs_big_reduce, dim3(nb), dim3(128), 0, h->stream, n, nb, P, pv, Ap, dots, scal);
+      hipLaunchKernelGGL(k_cgs_big_update, dim3(1), dim3(1024), 0, h->stream, n, nb, it, rtol2, r, pv, Ap, dots, x_t, scal);
+    }
+    SFM_HIP(h, hipMemcpyAsync(h->pinned, scal, 8 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    SFM_HIP(h, hipStreamSynchronize(h->stream));
+    if (h->pinned[CGS_FAIL] != 0.0) break;
+    const double rr = h->pinned[CGS_RR], rr0 = h->pinned[CGS_RR0];
+    if (rr <= rtol2 * rr0) { *status = 0; break; }
+    // next look where the residual should be small enough, from the average rate so far (as cgs_solve)
+    const double done_its = h->pinned[CGS_ITER] > 1.0 ? h->pinned[CGS_ITER] : 1.0;
+    const double rate = std::log(rr / rr0) / done_its;
+    batch = 8;
+    if (rate < -1e-3 && rr > 0.0) {
+      const double need = std::log(rtol2 * rr0 / rr) / rate;
+      batch = need < 2.0 ? 2 : (need > 48.0 ? 48 : (int)need + 2);
+    }
+  }
+  *iters_out += (int)h->pinned[CGS_ITER];
+  SFM_LAUNCH_CHECK(h, "cgs_solve_big");
+  return SFM_OK;
+}
+
 // point back-substitution for the p_c in the workspace, and (want_q) the pieces of rhs2 = p_c - W C_a^-1 p_p
 static void launch_backsub(sfm_ctx* h, sfm_ba_problem p, const Lay& L, double* ws, int want_q) {
   const int C = p->n_cams, P = p->n_pts, D = p->cam_dim, n = C * D;
@@ -2048,7 +2240,7 @@ extern "C" int sfm_ba_schur_solve(sfm_handle h, sfm_ba_problem p, double alpha, 
   p->cg_state = 0;
   p->cg2_pending = 0;
   p->cg_alpha = alpha;
-  if (p->camera_solver != SFM_CAMERA_SOLVER_CHOLESKY && n <= CGS_MAX_N && (n & 1) == 0) {
+  if (p->camera_solver != SFM_CAMERA_SOLVER_CHOLESKY && (n & 1) == 0 && cgs_big_allowed(n)) {
     // S~ = E^-1 (S + alpha I) E^-T into the factor's buffer (S stays as it is: the fallback below needs it), r~ = E^-1 r
     sfm_prof_begin(h, SFM_PROF_CHOL);
     SFM_HIP(h, hipMemsetAsync(WS(L, cg_scal), 0, 16 * sizeof(double), h->stream));
@@ -2098,7 +2290,7 @@ extern "C" int sfm_ba_schur_solve(sfm_handle h, sfm_ba_problem p, double alpha, 
     }
     if (!ran) {                                       // launch per iteration, with the scaling of r and of the solution as kernels of their own
       DISPATCH_D(D, hipLaunchKernelGGL(k_block_mv<DD>, dim3(cdiv(n, 256)), dim3(256), 0, h->stream, C, WS(L, cg_Minv), S + (size_t)n * n, WS(L, cg_r), 0, 1.0));
-      rc = cgs_solve(h, n, dw.Lm, WS(L, cg_r), WS(L, cg_z), dw.LmT, WS(L, cg_scal), CGS_RTOL, &p->cg_iters, &status); if (rc) return rc;
+      rc = (n <= CGS_MAX_N ? cgs_solve : cgs_solve_big)(h, n, dw.Lm, WS(L, cg_r), WS(L, cg_z), dw.LmT, WS(L, cg_scal), CGS_RTOL, &p->cg_iters, &status); if (rc) return rc;
       if (status == 0)
         DISPATCH_D(D, hipLaunchKernelGGL(k_block_mv<DD>, dim3(cdiv(n, 256)), dim3(256), 0, h->stream, C, WS(L, cg_Minv), WS(L, cg_z),
                                          WS(L, pc), 1, -1.0));                      // p_c = -E^-T x~
@@ -2200,7 +2392,7 @@ extern "C" int sfm_ba_finish_solve(sfm_handle h, sfm_ba_problem p, int want_q) {
         hipLaunchKernelGGL(k_add_vec, dim3(cdiv(n, 256)), dim3(256), 0, h->stream, WS(L, pc), WS(L, red_q), WS(L, tvec), n);
         DISPATCH_D(D, hipLaunchKernelGGL(k_block_mv<DD>, dim3(cdiv(n, 256)), dim3(256), 0, h->stream, C, WS(L, cg_Minv), WS(L, tvec),
                                          WS(L, cg_r), 0, 1.0));
-        rc = cgs_solve(h, n, dw.Lm, WS(L, cg_r), WS(L, cg_z), dw.LmT, WS(L, cg_scal), CGS_RTOL, &p->cg_iters, &status); if (rc) return rc;
+        rc = (n <= CGS_MAX_N ? cgs_solve : cgs_solve_big)(h, n, dw.Lm, WS(L, cg_r), WS(L, cg_z), dw.LmT, WS(L, cg_scal), CGS_RTOL, &p->cg_iters, &status); if (rc) return rc;
         if (status == 0)
           hipLaunchKernelGGL(k_dot, dim3(1), dim3(1024), 0, h->stream, n, WS(L, cg_r), WS(L, cg_z), WS(L, cg_scal) + 8);
       }
