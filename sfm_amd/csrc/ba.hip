@@ -2018,7 +2018,7 @@ static int cgs_solve(sfm_ctx* h, int n, const double* St, const double* rhs_t, d
 }
 
 // ------------------------------------------------------------------------------------ the same CG for large systems
-// n > CGS_MAX_N (1000 cameras: n = 10,000, S~ = 800 MB).  Nothing of S~ stays in a cache between iterations, so an iteration is
+// n > 2,048 (1000 cameras: n = 10,000, S~ = 800 MB).  Little of S~ stays in a cache between iterations, so an iteration is
 // a stream over the matrix and what counts is how many bytes of it are read: S~ is symmetric, and a 128 x 128 tile (I, J),
 // J < I, of its lower triangle serves BOTH products it takes part in - rows I of S~ p get A_IJ p_J, rows J get A_IJ^T p_I -
 // so an iteration reads n^2 / 2 entries (414 MB at n = 10,000 against 800 MB; the factorisation it replaces: 14 ms per damped
@@ -2167,12 +2167,20 @@ __global__ __launch_bounds__(1024) void k_cgs_big_update(int n, int nb, int it, 
   }
 }
 
-// SFM_CGS_BIG=0: systems beyond CGS_MAX_N take the factorisation as before round 3 (looked at per solve: a test switches it)
-static bool cgs_big_allowed(int n) {
-  if (n <= CGS_MAX_N) return true;
+// Which launch-per-iteration CG a system of n unknowns takes when the persistent kernel does not apply: the tile-streaming
+// one (cgs_solve_big) from SFM_CGS_BIG_FROM unknowns on, k_cgs_iter below.  Default: everything beyond the persistent kernel's
+// 2,048 - measured at n = 3,000 / 4,000: camera-solve slots 392 + 356 -> 329 + 290 us and 583 + 520 -> 422 + 348 us per damped
+// solve against k_cgs_iter<8, 4> (half the bytes per iteration outweigh two more launches).  SFM_CGS_BIG=0 switches the
+// tile-streaming route off: systems beyond CGS_MAX_N then take the factorisation, as before round 3.  Looked at per solve (a
+// test switches it).
+static bool cgs_use_big(int n) {
   const char* e = getenv("SFM_CGS_BIG");
-  return !(e && e[0] == '0');
+  if (e && e[0] == '0') return false;
+  const char* f = getenv("SFM_CGS_BIG_FROM");
+  const int from = f ? (atoi(f) > 256 ? atoi(f) : 257) : PR_MAX_N + 1;
+  return n >= from;
 }
+static bool cgs_possible(int n) { return (n & 1) == 0 && (n <= CGS_MAX_N || cgs_use_big(n)); }
 static int cgs_solve_big(sfm_ctx* h, int n, const double* St, const double* rhs_t, double* x_t, double* buf, double* scal,
                          double rtol, int* iters_out, int* status) {
   const double rtol2 = rtol * rtol;
@@ -2240,7 +2248,7 @@ extern "C" int sfm_ba_schur_solve(sfm_handle h, sfm_ba_problem p, double alpha, 
   p->cg_state = 0;
   p->cg2_pending = 0;
   p->cg_alpha = alpha;
-  if (p->camera_solver != SFM_CAMERA_SOLVER_CHOLESKY && (n & 1) == 0 && cgs_big_allowed(n)) {
+  if (p->camera_solver != SFM_CAMERA_SOLVER_CHOLESKY && cgs_possible(n)) {
     // S~ = E^-1 (S + alpha I) E^-T into the factor's buffer (S stays as it is: the fallback below needs it), r~ = E^-1 r
     sfm_prof_begin(h, SFM_PROF_CHOL);
     SFM_HIP(h, hipMemsetAsync(WS(L, cg_scal), 0, 16 * sizeof(double), h->stream));
@@ -2290,7 +2298,7 @@ extern "C" int sfm_ba_schur_solve(sfm_handle h, sfm_ba_problem p, double alpha, 
     }
     if (!ran) {                                       // launch per iteration, with the scaling of r and of the solution as kernels of their own
       DISPATCH_D(D, hipLaunchKernelGGL(k_block_mv<DD>, dim3(cdiv(n, 256)), dim3(256), 0, h->stream, C, WS(L, cg_Minv), S + (size_t)n * n, WS(L, cg_r), 0, 1.0));
-      rc = (n <= CGS_MAX_N ? cgs_solve : cgs_solve_big)(h, n, dw.Lm, WS(L, cg_r), WS(L, cg_z), dw.LmT, WS(L, cg_scal), CGS_RTOL, &p->cg_iters, &status); if (rc) return rc;
+      rc = (cgs_use_big(n) ? cgs_solve_big : cgs_solve)(h, n, dw.Lm, WS(L, cg_r), WS(L, cg_z), dw.LmT, WS(L, cg_scal), CGS_RTOL, &p->cg_iters, &status); if (rc) return rc;
       if (status == 0)
         DISPATCH_D(D, hipLaunchKernelGGL(k_block_mv<DD>, dim3(cdiv(n, 256)), dim3(256), 0, h->stream, C, WS(L, cg_Minv), WS(L, cg_z),
                                          WS(L, pc), 1, -1.0));                      // p_c = -E^-T x~
@@ -2392,7 +2400,7 @@ extern "C" int sfm_ba_finish_solve(sfm_handle h, sfm_ba_problem p, int want_q) {
         hipLaunchKernelGGL(k_add_vec, dim3(cdiv(n, 256)), dim3(256), 0, h->stream, WS(L, pc), WS(L, red_q), WS(L, tvec), n);
         DISPATCH_D(D, hipLaunchKernelGGL(k_block_mv<DD>, dim3(cdiv(n, 256)), dim3(256), 0, h->stream, C, WS(L, cg_Minv), WS(L, tvec),
                                          WS(L, cg_r), 0, 1.0));
-        rc = (n <= CGS_MAX_N ? cgs_solve : cgs_solve_big)(h, n, dw.Lm, WS(L, cg_r), WS(L, cg_z), dw.LmT, WS(L, cg_scal), CGS_RTOL, &p->cg_iters, &status); if (rc) return rc;
+        rc = (cgs_use_big(n) ? cgs_solve_big : cgs_solve)(h, n, dw.Lm, WS(L, cg_r), WS(L, cg_z), dw.LmT, WS(L, cg_scal), CGS_RTOL, &p->cg_iters, &status); if (rc) return rc;
         if (status == 0)
           hipLaunchKernelGGL(k_dot, dim3(1), dim3(1024), 0, h->stream, n, WS(L, cg_r), WS(L, cg_z), WS(L, cg_scal) + 8);
       }
