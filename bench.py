@@ -252,7 +252,7 @@ def main():
         return r
 
     bytes_per_obs = 8 + 16 + 16 + 2 * d * 8 + 48
-    big_cg = n_sys > 4096 and os.environ.get("SFM_CGS_BIG", "1") != "0"
+    big_cg = n_sys >= int(os.environ.get("SFM_CGS_BIG_FROM", "2049")) and os.environ.get("SFM_CGS_BIG", "1") != "0"
     cg_on = args.camera_solver != "cholesky" and (n_sys <= 4096 or big_cg)
     cam_roofs = []
     if cg_on and "chol" in kernels:

@@ -130,14 +130,15 @@ int sfm_match_f32_to_u8(sfm_handle h, const float* src, int64_t n_elems, uint8_t
 
 /* What bundle_adjust packs before it calls SciPy (sfm_reconstruction.py:409-451) - nothing kernel-specific.
  * cam_idx / pt_idx / uv may be host or device pointers; sfm_ba_create_problem copies them. */
-enum { SFM_CAMERA_SOLVER_AUTO = 0,       /* CG when n = n_cams * cam_dim <= 4096, else the factorisation (default) */
+enum { SFM_CAMERA_SOLVER_AUTO = 0,       /* CG on the block-scaled system (n = n_cams * cam_dim even), the factorisation as its fallback (default) */
        SFM_CAMERA_SOLVER_CHOLESKY = 1,   /* bordered dense Cholesky + triangular solves */
-       SFM_CAMERA_SOLVER_CG = 2 };       /* conjugate gradients on the block-scaled system (n <= 4096), relative residual
-                                            1e-13 (~25 iterations at 200 cameras): ONE persistent launch per system for
-                                            n <= 2048 (the matrix rows in registers, the product all-gathered between
-                                            workgroups through self-validating 8-byte granules), one launch per iteration
-                                            above; falls back to the factorisation when it does not converge in 160
-                                            iterations or meets non-positive curvature */
+       SFM_CAMERA_SOLVER_CG = 2 };       /* conjugate gradients on the block-scaled system, relative residual 1e-13 (~25 iterations
+                                            at 200 cameras, ~40 at 1000): ONE persistent launch per system for n <= 2048 (the
+                                            matrix rows in registers, the product all-gathered between workgroups through
+                                            self-validating 8-byte granules); beyond, three launches per iteration that stream
+                                            the 128 x 128 tiles of the LOWER triangle only (a tile serves both products it takes
+                                            part in; partial sums added in fixed order); falls back to the factorisation when it
+                                            does not converge (160 / 400 iterations) or meets non-positive curvature */
 enum { SFM_BA_FP64 = 0,    /* every intermediate in float64 (default; the reference's arithmetic) */
        SFM_BA_MIXED = 1 }; /* Jacobian rows (and scaled residuals) stored in float32; every sum, W L^-T, S and the solve in float64 */
 typedef struct {
