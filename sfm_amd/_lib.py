@@ -6,7 +6,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libsfm_amd.so")
+# SFM_AMD_LIB: a diagnostic build of the same library (tools/exp_*.sh); there is no other library to fall back to
+LIB_PATH = os.environ.get("SFM_AMD_LIB") or os.path.join(_HERE, "lib", "libsfm_amd.so")
 
 METRIC_L2_U8, METRIC_L2_F32, METRIC_HAMMING = 0, 1, 2
 (SC_COST, SC_GNORM2, SC_GINF, SC_PNORM2, SC_PQ, SC_JS2, SC_GTS, SC_COST_NEW, SC_SNORM2,

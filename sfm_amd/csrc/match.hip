@@ -23,6 +23,7 @@
 #include "common.h"
 #include "match_plan.h"
 #include <cstdlib>
+#include <cstdio>
 #include <vector>
 #include <type_traits>
 
@@ -441,10 +442,33 @@ __global__ __launch_bounds__(256) void k_train_tile_u8(const uint8_t* __restrict
   if (threadIdx.x < 2) pb_t[tile * 2 + threadIdx.x] = s_pb[threadIdx.x];
 }
 
+// Diagnostic build only (-DSFM_MATCH_STAMPS=1, tools/exp_matcher_lifetimes.sh): begin / end of every wave of the direct kernel on
+// the 100 MHz constant clock, with the place it ran (HW_ID, XCC_ID).  The shipped library executes no stamp.
+// train rows per workgroup, first : second on a CU (k_knn2_u8_direct).  Measured at 50k x 50k, distance kernel by HIP events:
+// even 378 us, 128:100 370, 135:100 367-368, 150:100 367 (the wave end stamps then lie within 306-354 us instead of 283-375)
+constexpr int MATCH_W_FIRST = 135, MATCH_W_SECOND = 100;
+#ifndef SFM_MATCH_STAMPS
+#define SFM_MATCH_STAMPS 0
+#endif
+#if SFM_MATCH_STAMPS
+__device__ unsigned long long g_match_stamps[4 * 4096 * 4];
+extern "C" int sfm_debug_match_stamps(unsigned long long* dst, int n_words) {
+  return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_match_stamps), (size_t)n_words * 8, 0, hipMemcpyDeviceToHost);
+}
+#define MATCH_STAMP_BEGIN() const unsigned long long stamp_t0 = __builtin_amdgcn_s_memrealtime()
+#define MATCH_STAMP_END() do { if ((threadIdx.x & 63) == 0 && blockIdx.x < 4096) { \
+    unsigned long long* o = g_match_stamps + ((size_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 4; \
+    o[0] = stamp_t0; o[1] = __builtin_amdgcn_s_memrealtime(); \
+    o[2] = (unsigned)__builtin_amdgcn_s_getreg((31 << 11) | 4); o[3] = (unsigned)__builtin_amdgcn_s_getreg((31 << 11) | 20); } } while (0)
+#else
+#define MATCH_STAMP_BEGIN() do {} while (0)
+#define MATCH_STAMP_END() do {} while (0)
+#endif
 template <int QB>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(QB == 2 ? 3 : 2, QB == 2 ? 3 : 2))) void k_knn2_u8_direct(
     const uint8_t* __restrict__ q, int64_t nq, const uint8_t* __restrict__ xt, int64_t nt, const int* __restrict__ th_t,
-    const int* __restrict__ pb_t, const int* __restrict__ qn, int nsplit, int64_t rows_per_split, Cand* __restrict__ part, int* u2g) {
+    const int* __restrict__ pb_t, const int* __restrict__ qn, int nsplit, int64_t rows_per_split, Cand* __restrict__ part, int* u2g,
+    int w_first, int w_second) {
   constexpr int KS = 4, DIM = 128;
   static_assert(QB % 2 == 0, "the two accumulators alternate by step across tiles");
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, half = lane >> 5, l31 = lane & 31;
@@ -456,10 +480,36 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(QB == 2 ? 3
   const int n_qblocks = nb / nsplit;
   const int split = id / n_qblocks;
   const int64_t qblock = id - split * n_qblocks;
-  const int64_t t_beg = (int64_t)split * rows_per_split;                 // a multiple of 128
-  const int64_t t_end = (t_beg + rows_per_split) < nt ? (t_beg + rows_per_split) : nt;
+  int64_t t_beg = (int64_t)split * rows_per_split;                       // a multiple of 128
+  int64_t t_end = (t_beg + rows_per_split) < nt ? (t_beg + rows_per_split) : nt;
+  if (w_first > 0) {
+    // Uneven splits (single-round grids, two workgroups per CU).  Measured with begin / end stamps per wave (tools/
+    // exp_matcher_lifetimes.sh, 50k x 50k): all 490 workgroups start within 0.4 us, the workgroup that reached its CU FIRST
+    // finishes after 300 us, the one that came second after 362 (vector issue between the two waves of a SIMD is arbitrated
+    // by age: MI355X_MICROARCH.md, Two waves per SIMD, item 2), and for the last sixth of the launch every SIMD runs one wave.
+    // Which of the two a workgroup is could be told from its place in its XCD's dispatch sequence in 458 of 458 cases:
+    // (blockIdx >> 3) < 32 CUs <=> first.  So the train rows of a query block are cut in proportion to the rate its
+    // workgroups are expected to run at (w_first : w_second), in units of 128 rows.  Speed only: any cut gives the same
+    // neighbours (the merge is exact), and a placement other than the assumed one just leaves the old imbalance.
+    const int64_t chunks = (nt + 127) >> 7;
+    int cum = 0, tot = 0, mine = 0;
+    for (int s2 = 0; s2 < nsplit; ++s2) {
+      const int idu = s2 * n_qblocks + (int)qblock;
+      int x = 0;
+      while (x < 7 && (x + 1) * per + ((x + 1) < rem ? (x + 1) : rem) <= idu) ++x;
+      const int j = idu - (x * per + (x < rem ? x : rem));
+      const int wt = j < 32 ? w_first : w_second;
+      if (s2 < split) cum += wt;
+      if (s2 == split) mine = wt;
+      tot += wt;
+    }
+    t_beg = (chunks * cum / tot) << 7;
+    t_end = split == nsplit - 1 ? nt : ((chunks * (cum + mine) / tot) << 7);
+    if (t_end > nt) t_end = nt;
+  }
   const int64_t q0 = qblock * (4 * QB * 32) + (int64_t)w * (QB * 32);
   if (q0 >= nq) return;                                                  // waves are independent: no barrier below
+  MATCH_STAMP_BEGIN();
 
   v4i bq[QB][KS];
   // What only the window flush touches (the running best two, the posted bound, QN) lives in LDS between flushes - the
@@ -662,6 +712,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(QB == 2 ? 3
       o[1].d = b2i >= 0 ? b2d : 0.0f; o[1].i = b2i;
     }
   }
+  MATCH_STAMP_END();
 }
 
 // ------------------------------------------------------------------------------------ generic VALU kernel
@@ -961,8 +1012,18 @@ static int match_launch(sfm_ctx* h, int metric, const void* q, int64_t nq_rows, 
     sfm_prof_begin(h, SFM_PROF_KNN);
 #define KNN_LAUNCH(KS, QB, F) hipLaunchKernelGGL((k_knn2_u8<KS, QB, F>), dim3(grid), dim3(256), 0, h->stream, q8, nq_rows, w.tf, nt_rows, w.th, w.par, w.qn, nsplit, rps, wg, n_out, w.part, w.u2)
     if (direct) {
-      if (direct2) hipLaunchKernelGGL((k_knn2_u8_direct<2>), dim3(grid), dim3(256), 0, h->stream, q8, nq_rows, w.tf, nt_rows, w.th, w.par, w.qn, nsplit, rps, w.part, w.u2);
-      else hipLaunchKernelGGL((k_knn2_u8_direct<4>), dim3(grid), dim3(256), 0, h->stream, q8, nq_rows, w.tf, nt_rows, w.th, w.par, w.qn, nsplit, rps, w.part, w.u2);
+      // uneven train splits for the two workgroups of a CU (see the kernel): grids of one round at two workgroups per CU only
+      // (256 < grid <= 512, four query blocks per wave), splits long enough to cut.  SFM_MATCH_SPLIT_W="first:second" overrides,
+      // "0" = even splits
+      int w_first = 0, w_second = 0;
+      if (!direct2 && grid > 256 && grid <= 512 && nsplit > 1 && nt_rows / nsplit >= 2048) { w_first = MATCH_W_FIRST; w_second = MATCH_W_SECOND; }
+      if (const char* we = getenv("SFM_MATCH_SPLIT_W")) {
+        int a = 0, b = 0;
+        if (sscanf(we, "%d:%d", &a, &b) == 2 && a > 0 && b > 0 && a <= 1024 && b <= 1024 && nsplit > 1) { w_first = a; w_second = b; }
+        else { w_first = w_second = 0; }
+      }
+      if (direct2) hipLaunchKernelGGL((k_knn2_u8_direct<2>), dim3(grid), dim3(256), 0, h->stream, q8, nq_rows, w.tf, nt_rows, w.th, w.par, w.qn, nsplit, rps, w.part, w.u2, w_first, w_second);
+      else hipLaunchKernelGGL((k_knn2_u8_direct<4>), dim3(grid), dim3(256), 0, h->stream, q8, nq_rows, w.tf, nt_rows, w.th, w.par, w.qn, nsplit, rps, w.part, w.u2, w_first, w_second);
     } else if (filter) {
       if (qb4) KNN_LAUNCH(4, 4, true); else if (dim == 256) KNN_LAUNCH(8, 2, true); else if (dim == 128) KNN_LAUNCH(4, 2, true); else if (dim == 64) KNN_LAUNCH(2, 2, true); else KNN_LAUNCH(1, 2, true);
     } else {
