@@ -586,10 +586,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(QB == 2 ? 3
         const int r = 4 * g + j;
         // ((2 acc + parity) << 8) | row in window = ((d^2 - QN) << 8) | row
         const int key = (a[r] << 9) + ((((pbits >> r) & 1) << 8) + (wb + 8 * g + j));
-        int nm2;
-        asm("v_med3_i32 %0, %1, %2, %3" : "=v"(nm2) : "v"(m1[qb][r & 1]), "v"(m2[qb][r & 1]), "v"(key));
-        m2[qb][r & 1] = nm2;
-        m1[qb][r & 1] = min(m1[qb][r & 1], key);
+        // both updates IN PLACE (tied operands): with a separate result register the compiler kept every query block's four
+        // values in two homes and copied them from one to the other after every step, ranked or not (4 of ~16 vector
+        // instructions of a step nothing was ranked in)
+        asm("v_med3_i32 %0, %1, %0, %2" : "+v"(m2[qb][r & 1]) : "v"(m1[qb][r & 1]), "v"(key));
+        asm("v_min_i32 %0, %0, %1" : "+v"(m1[qb][r & 1]) : "v"(key));
       }
     }
   };
@@ -683,11 +684,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(QB == 2 ? 3
     }
   };
   if (n_tiles > 0) load_tile(tile0, 0);
-  for (int t = 0; t < n_tiles; t += 2) {
+  // pairs of tiles in a loop with ONE exit, an odd last tile after it: with `if (t + 1 >= n_tiles) break;` between the two
+  // halves of the body the compiler kept the running keys of every query block in two register homes, one per exit, and
+  // copied them from one to the other after every step (4 of the ~16 vector instructions of a step nothing is ranked in)
+  for (int t = 0; t + 1 < n_tiles; t += 2) {
     do_tile(t, 0);
-    if (t + 1 >= n_tiles) break;
     do_tile(t + 1, 1);
   }
+  if (n_tiles & 1) do_tile(n_tiles - 1, 0);
   if (n_tiles > 0) {                                       // the last step's ranking and the last window
     const int t = n_tiles - 1, set = t & 1;
 #pragma unroll
