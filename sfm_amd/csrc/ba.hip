@@ -674,8 +674,36 @@ __global__ __launch_bounds__(256) void k_build_G(int64_t N, const int* __restric
 #define SFM_SCHUR_U_D10 SFM_SCHUR_U
 #define SFM_SCHUR_U_D6 SFM_SCHUR_U
 #endif
+// Diagnostic build only (-DSFM_SCHUR_STAMPS=1, tools/exp_schur_lifetimes.sh): begin / end of every wave of k_schur_items on the
+// 100 MHz constant clock, with its item's pair count and the place it ran.  The shipped library executes no stamp.
+#ifndef SFM_SCHUR_STAMPS
+#define SFM_SCHUR_STAMPS 0
+#endif
+#if SFM_SCHUR_STAMPS
+constexpr int SCHUR_STAMP_WAVES = 1 << 16;
+__device__ unsigned long long g_schur_stamps[SCHUR_STAMP_WAVES * 4];
+extern "C" int sfm_debug_schur_stamps(unsigned long long* dst, int n_words) {
+  return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_schur_stamps), (size_t)n_words * 8, 0, hipMemcpyDeviceToHost);
+}
+#define SCHUR_STAMP_BEGIN() const unsigned long long stamp_t0 = __builtin_amdgcn_s_memrealtime()
+#define SCHUR_STAMP_END(npairs) do { const unsigned wv = blockIdx.x * SFM_SCHUR_WG_WAVES + (threadIdx.x >> 6); if ((threadIdx.x & 63) == 0 && wv < SCHUR_STAMP_WAVES) { \
+    unsigned long long* o = g_schur_stamps + (size_t)wv * 4; \
+    o[0] = stamp_t0; o[1] = __builtin_amdgcn_s_memrealtime(); \
+    o[2] = ((unsigned long long)(unsigned)(npairs) << 32) | (unsigned)__builtin_amdgcn_s_getreg((31 << 11) | 4); \
+    o[3] = (unsigned)__builtin_amdgcn_s_getreg((31 << 11) | 20); } } while (0)
+#else
+#define SCHUR_STAMP_BEGIN() do {} while (0)
+#define SCHUR_STAMP_END(npairs) do {} while (0)
+#endif
+// waves per workgroup of k_schur_items (its waves never meet: no barrier, wave-private LDS).  ONE: a wave slot is handed back
+// when its wave ends, not when the slowest of four does.  Wave begin / end stamps (tools/exp_schur_lifetimes.sh, cfg4): with
+// four waves per workgroup 4,400-4,800 of the 5,120 wave slots were occupied through the bulk of the launch, with one 4,850-
+// 5,050; span 309-311 -> 302-303 us (a wave lives 53 -> 55 us: the gather is bandwidth-bound, the gain is the filled slots).
+#ifndef SFM_SCHUR_WG_WAVES
+#define SFM_SCHUR_WG_WAVES 1
+#endif
 template <int D, typename T, int GS, bool KPACK, bool NTK2>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(D == 6 ? SFM_SCHUR_WAVES_D6 : SFM_SCHUR_WAVES_D10, D == 6 ? SFM_SCHUR_WAVES_D6 : SFM_SCHUR_WAVES_D10))) void k_schur_items(const int* __restrict__ xcd_ptr, const int* __restrict__ xcd_items,
+__global__ __launch_bounds__(64 * SFM_SCHUR_WG_WAVES) __attribute__((amdgpu_waves_per_eu(D == 6 ? SFM_SCHUR_WAVES_D6 : SFM_SCHUR_WAVES_D10, D == 6 ? SFM_SCHUR_WAVES_D6 : SFM_SCHUR_WAVES_D10))) void k_schur_items(const int* __restrict__ xcd_ptr, const int* __restrict__ xcd_items,
                                                      const int* __restrict__ item_beg,
                                                      const int* __restrict__ item_end,
                                                      const int* __restrict__ pair_k, const int* __restrict__ pair_k2,
@@ -705,15 +733,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(D == 6 ? SF
   constexpr int UMAX = D == 6 ? SFM_SCHUR_U_D6 : SFM_SCHUR_U_D10;
   constexpr int U = (64 + BPL - 1) / BPL < UMAX ? (64 + BPL - 1) / BPL : UMAX;   // load instructions in flight per operand
   constexpr int PB = U * BPL;                  // pairs per batch
-  __shared__ __attribute__((aligned(16))) char s_stage[4][2][BPL * BB];
-  __shared__ double s_e[4][64][3];             // diagonal items: e_j of the 64 pairs whose ids the wave holds
+  constexpr int WGW = SFM_SCHUR_WG_WAVES;
+  __shared__ __attribute__((aligned(16))) char s_stage[WGW][2][BPL * BB];
+  __shared__ double s_e[WGW][64][3];           // diagonal items: e_j of the 64 pairs whose ids the wave holds
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  // workgroup b serves item group b % 8 (block rows c = b % 8 mod 8): with the round-robin XCD placement one
+  // workgroup b serves item group b % 8 (a set of whole block rows, problem.hip): with the round-robin XCD placement one
   // XCD sees every item of a camera's block row, so that camera's G blocks (1.2 MB at 5,000 observations) are
   // re-read from its 4 MB L2 instead of the fabric (speed only - any placement gives the same result)
   const int grp = blockIdx.x & 7;
-  const int pos = xcd_ptr[grp] + (blockIdx.x >> 3) * 4 + w;
+  const int pos = xcd_ptr[grp] + (blockIdx.x >> 3) * WGW + w;
   if (pos >= xcd_ptr[grp + 1]) return;
+  SCHUR_STAMP_BEGIN();
   const int it = xcd_items[pos];
   const int beg = item_beg[it], end = item_end[it];
   const int row = lane & 15, m = lane >> 4;
@@ -831,6 +861,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(D == 6 ? SF
       if (rr < D) cch_part[(size_t)ch * 16 + rr] = acc[i];
     }
   }
+  SCHUR_STAMP_END(end - beg);
 }
 
 // grid (C, ceil(C/2)); 128 threads per block pair (c, c2): thread e < D*D owns element (e / D, e % D).
@@ -1380,8 +1411,8 @@ extern "C" int sfm_ba_schur_build(sfm_handle h, sfm_ba_problem p, double alpha) 
       static const bool kpack = !(getenv("SFM_SCHUR_KPACK") && getenv("SFM_SCHUR_KPACK")[0] == '0');
       static const bool ntk2 = getenv("SFM_SCHUR_NT") && getenv("SFM_SCHUR_NT")[0] == '1';    // experiment: non-temporal k2-side loads
       auto schur_items = [&](auto kp, auto nt) {
-        hipLaunchKernelGGL((k_schur_items<DD, double, GG, decltype(kp)::value, decltype(nt)::value>), dim3(8 * cdiv(p->xcd_max_items, 4)),
-                           dim3(256), 0, h->stream,
+        hipLaunchKernelGGL((k_schur_items<DD, double, GG, decltype(kp)::value, decltype(nt)::value>), dim3(8 * cdiv(p->xcd_max_items, SFM_SCHUR_WG_WAVES)),
+                           dim3(64 * SFM_SCHUR_WG_WAVES), 0, h->stream,
                            p->xcd_ptr, p->xcd_items, p->item_beg, p->item_end, p->pair_k, p->pair_k2, WS(L, G), WS(L, sch_part),
                            p->cam_idx, p->item_ptr, p->cch_ptr, C, WS(L, eobs), WS(L, cch_part), p->has_dup ? 0 : 1);
       };

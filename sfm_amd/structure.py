@@ -112,7 +112,7 @@ def build_structure(cam_idx, pt_idx, n_cams, n_pts):
     i32 = lambda a: np.ascontiguousarray(a, dtype=np.int32)
     item_ptr, item_beg, item_end = _split_ranges(blk_ptr, ITEM_PAIRS)
     cch_ptr, cch_beg, cch_end = _split_ranges(cam_ptr, CHUNK_OBS)
-    # block row of every item -> 8 groups (stable: rows, then blocks, stay in order inside a group): row mod 8, or with
+    # block row of every item -> 8 groups (stable: rows, then blocks, stay in order inside a group): rows dealt back and forth, or with
     # SFM_XCD_GROUP=contig contiguous row ranges balanced by item count (the same rule as sfm_amd/csrc/problem.hip)
     n_blk_row = np.arange(n_cams, 0, -1, dtype=np.int64)                 # row c holds blocks (c, c..C-1)
     blk_row = np.repeat(np.arange(n_cams, dtype=np.int64), n_blk_row)
@@ -123,7 +123,8 @@ def build_structure(cam_idx, pt_idx, n_cams, n_pts):
         mid = np.cumsum(row_cnt) - row_cnt + row_cnt // 2
         row_grp = np.minimum((mid * 8) // max(total, 1), 7) if total > 0 else np.zeros(n_cams, dtype=np.int64)
     else:
-        row_grp = np.arange(n_cams, dtype=np.int64) % 8
+        r = np.arange(n_cams, dtype=np.int64)
+        row_grp = np.where(r & 8, 7 - (r & 7), r & 7)        # dealt back and forth: balances the shrinking rows over the groups
     item_grp = row_grp[item_row]
     xcd_items = np.argsort(item_grp, kind="stable")
     xcd_ptr = np.zeros(9, dtype=np.int64)
