@@ -16,9 +16,9 @@ cd /tmp && export TMPDIR=/tmp
 BA="--no-cpu-baseline --no-matcher --no-d6 --no-mixed --no-pcg --no-dropin --no-driver-rows --no-alt-camera-solver --no-coherent"
 echo "[1/7] bench line (defaults)";           python3 $R/bench.py > $OUT/bench.json 2> $OUT/bench.err || exit 1
 echo "[2/7] kernel trace + stats (BA + matcher)"
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt -- python3 $R/bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-d6 --no-mixed --no-pcg --no-dropin --no-driver-rows --no-alt-camera-solver --no-coherent > $OUT/kt.log 2>&1 || exit 1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt -- python3 $R/bench.py --steps 10 --warmup 5 --no-cpu-baseline --no-d6 --no-mixed --no-pcg --no-dropin --no-driver-rows --no-alt-camera-solver --no-coherent > $OUT/kt.log 2>&1 || exit 1
 echo "[2b/7] kernel trace + stats with the factorisation forced"
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/ktc -- python3 $R/bench.py --steps 4 --warmup 2 --camera-solver cholesky $BA > $OUT/ktc.log 2>&1 || exit 1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/ktc -- python3 $R/bench.py --steps 6 --warmup 3 --camera-solver cholesky $BA > $OUT/ktc.log 2>&1 || exit 1
 echo "[3/7] PMC FETCH_SIZE";  rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/fetch -- python3 $R/bench.py --steps 2 --warmup 1 $BA > $OUT/fetch.log 2>&1 || exit 1
 echo "[4/7] PMC WRITE_SIZE";  rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/write -- python3 $R/bench.py --steps 2 --warmup 1 $BA > $OUT/write.log 2>&1 || exit 1
 echo "[4b/7] PMC FETCH_SIZE on the spatially coherent scene, L2 hit counters on both scenes"
