@@ -366,6 +366,7 @@ def main():
         rc2 = fixed_schedule_run(d, "fp64", True, shard=shard_scene(sc2))
         ba_coherent = brief(rc2, "same sizes, spatially coherent visibility (synth.make_scene(visibility='nearest')): each point seen by "
                                  "its L nearest cameras, cameras numbered along the hemisphere")
+        ba_coherent["camera_cg_iterations_and_fallbacks_incl_warmup"] = rc2["camera_cg"]
         ba_coherent["kernels_us"] = {k: round(v[0] / v[1] * 1e3, 2) for k, v in rc2["prof"].items() if v[1] > 0}
         ba_coherent["n_pairs"] = rc2["n_pairs"]
         uq = rc2["n_obs_local"] * 3 * d * 8 + rc2["n_pairs"] * 8.0

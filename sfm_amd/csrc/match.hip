@@ -145,6 +145,8 @@ typedef __attribute__((address_space(3))) void* lptr_t;
 // dim 256 (KS = 8: Hamming-256 / ORB over unpacked bits) holds twice the query and operand fragments and spills 7-15 registers
 // at two waves per SIMD.  Measured (round 3, 30,000 x 30,000 x 256 bits): one wave per SIMD, no spills (-DSFM_KNN_KS8_WAVES=1)
 // 535 us = 1.68e12 pairs/s; two waves with the spills 429 us = 2.10e12 - the second wave is worth more than the spills cost.
+// Pairs of 8e6 distances and more no longer come here: they take k_knn2_u8_direct<2, 8> (no LDS, 230 registers, no spill in the
+// loop): 30,000 x 30,000: 461 -> 289 us per call = 3.1e12 pairs/s, 50,000 x 50,000: 1,130 -> 660 us = 3.8e12.
 #ifndef SFM_KNN_KS8_WAVES
 #define SFM_KNN_KS8_WAVES KNN_WAVES
 #endif
@@ -404,20 +406,24 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(KS == 8 ? S
 // lines - and every wave fetches its A operands with plain global loads one tile ahead: no LDS, no barrier, the waves
 // of a workgroup are independent (they hit the same lines in the CU's L1).  TN_i travels with the tile in register
 // order (16 values per half-wave); TH = TN >> 1 and the parity bit are taken from it in registers.
-__global__ __launch_bounds__(256) void k_train_tile_u8(const uint8_t* __restrict__ x, int64_t n, uint8_t* __restrict__ xt,
-                                                       int* __restrict__ th_t, int* __restrict__ pb_t, int* __restrict__ fix_cnt) {
-  __shared__ int s_pb[2];                                  // a workgroup = 256 threads = the 32 rows of ONE tile
+// Two widths: KS = 4 (dim 128: SIFT, 128-bit strings) and KS = 8 (256 unpacked bits: ORB, find_matches.py:144 - twice the
+// MFMAs per step for the same filter and ranking work, two query blocks per wave).
+template <int KS>   // KS = dim / 32: 4 (SIFT) or 8 (256 unpacked bits)
+__global__ __launch_bounds__(64 * KS) void k_train_tile_u8(const uint8_t* __restrict__ x, int64_t n, uint8_t* __restrict__ xt,
+                                                           int* __restrict__ th_t, int* __restrict__ pb_t, int* __restrict__ fix_cnt) {
+  constexpr int PPR = 2 * KS, DIM = 32 * KS;               // 16-byte pieces per row; a workgroup = 64 KS threads = the 32 rows of ONE tile
+  __shared__ int s_pb[2];
   if (threadIdx.x < 2) s_pb[threadIdx.x] = 0;
   if (blockIdx.x == 0 && threadIdx.x == 0) *fix_cnt = 0;    // the re-rank list of this call starts empty (filled by k_merge_splits_u8)
   __syncthreads();
-  const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  const int64_t r = t >> 3;                               // row (up to the end of the last 32-row tile)
-  const int gi = (int)(t & 7);                            // 16-byte piece of the row: k-slice gi >> 1, half gi & 1
+  const int64_t t = (int64_t)blockIdx.x * (64 * KS) + threadIdx.x;
+  const int64_t r = t / PPR;                              // row (up to the end of the last 32-row tile)
+  const int gi = (int)(t - r * PPR);                      // 16-byte piece of the row: k-slice gi >> 1, half gi & 1
   // the grid covers whole tiles (n rounded up to 32 rows): no thread leaves before the barrier below
   uint4 v = make_uint4(0u, 0u, 0u, 0u);
   int s = 0;
   if (r < n) {
-    v = *(const uint4*)(x + r * 128 + gi * 16);
+    v = *(const uint4*)(x + r * DIM + gi * 16);
     v.x ^= 0x80808080u; v.y ^= 0x80808080u; v.z ^= 0x80808080u; v.w ^= 0x80808080u;
     const uint32_t wds[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
@@ -430,9 +436,10 @@ __global__ __launch_bounds__(256) void k_train_tile_u8(const uint8_t* __restrict
   }
   const int64_t tile = r >> 5;
   const int l31 = (int)(r & 31);
-  *(uint4*)(xt + (((tile * 4 + (gi >> 1)) * 64) + (gi & 1) * 32 + l31) * 16) = v;
-  s += __shfl_xor(s, 1, 64); s += __shfl_xor(s, 2, 64); s += __shfl_xor(s, 4, 64);     // the 8 lanes of a row are adjacent and aligned
-  const int tn = (r < n) ? (s - 128) : 2 * SENT_TH;
+  *(uint4*)(xt + (((tile * KS + (gi >> 1)) * 64) + (gi & 1) * 32 + l31) * 16) = v;
+#pragma unroll
+  for (int o = 1; o < PPR; o <<= 1) s += __shfl_xor(s, o, 64);     // the 2 KS lanes of a row are adjacent and aligned
+  const int tn = (r < n) ? (s - DIM) : 2 * SENT_TH;
   // accumulator register rr of half-wave hh holds row (rr & 3) + 8 (rr >> 2) + 4 hh of the tile
   const int hh = (l31 >> 2) & 1, rr = (l31 & 3) + 4 * (l31 >> 3);
   if (gi == 0) th_t[(tile * 2 + hh) * 16 + rr] = tn >> 1;
@@ -442,8 +449,6 @@ __global__ __launch_bounds__(256) void k_train_tile_u8(const uint8_t* __restrict
   if (threadIdx.x < 2) pb_t[tile * 2 + threadIdx.x] = s_pb[threadIdx.x];
 }
 
-// Diagnostic build only (-DSFM_MATCH_STAMPS=1, tools/exp_matcher_lifetimes.sh): begin / end of every wave of the direct kernel on
-// the 100 MHz constant clock, with the place it ran (HW_ID, XCC_ID).  The shipped library executes no stamp.
 // train rows per workgroup, first : second on a CU (k_knn2_u8_direct).  Measured at 50k x 50k, distance kernel by HIP events:
 // even 378 us, 128:100 370, 135:100 367-368, 150:100 367 (the wave end stamps then lie within 306-354 us instead of 283-375)
 constexpr int MATCH_W_FIRST = 135, MATCH_W_SECOND = 100;
@@ -464,12 +469,12 @@ extern "C" int sfm_debug_match_stamps(unsigned long long* dst, int n_words) {
 #define MATCH_STAMP_BEGIN() do {} while (0)
 #define MATCH_STAMP_END() do {} while (0)
 #endif
-template <int QB>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(QB == 2 ? 3 : 2, QB == 2 ? 3 : 2))) void k_knn2_u8_direct(
+template <int QB, int KS = 4>   // KS = dim / 32: 4 (SIFT), 8 (256 unpacked bits: ORB)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((QB == 2 && KS == 4) ? 3 : 2, (QB == 2 && KS == 4) ? 3 : 2))) void k_knn2_u8_direct(
     const uint8_t* __restrict__ q, int64_t nq, const uint8_t* __restrict__ xt, int64_t nt, const int* __restrict__ th_t,
     const int* __restrict__ pb_t, const int* __restrict__ qn, int nsplit, int64_t rows_per_split, Cand* __restrict__ part, int* u2g,
     int w_first, int w_second) {
-  constexpr int KS = 4, DIM = 128;
+  constexpr int DIM = 32 * KS;
   static_assert(QB % 2 == 0, "the two accumulators alternate by step across tiles");
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, half = lane >> 5, l31 = lane & 31;
   // Workgroup -> (split, query block), split-major over the workgroups of one XCD (round-robin placement: XCD = b % 8):
@@ -558,7 +563,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(QB == 2 ? 3
 #undef QUAD_BCAST
   auto load_tile = [&](int64_t tile, int set) {
 #pragma unroll
-    for (int ks = 0; ks < KS; ++ks) at[set][ks] = *(const v4i*)(xt + ((tile * 4 + ks) * 64 + lane) * 16);
+    for (int ks = 0; ks < KS; ++ks) at[set][ks] = *(const v4i*)(xt + ((tile * KS + ks) * 64 + lane) * 16);
     // the 16 start values of a half-wave: every lane fetches ONE quarter (the quarter its position in its quad names), the
     // quads then pass the quarters round with DPP moves (spread_th).  Four 16-byte loads per lane instead of one would give
     // every lane all 16 directly - and cost the CU's single texture-address path 64 cycles per wave and tile instead of 16;
@@ -673,7 +678,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(QB == 2 ? 3
       for (int ks = 0; ks < KS; ++ks) {
         acc[qb & 1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(at[set][ks], bq[qb][ks], acc[qb & 1], 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
-        rank_group_min(prev, ks);
+        if (ks < 4) rank_group_min(prev, ks);              // the four group minima of the previous step: one per MFMA gap
         __builtin_amdgcn_sched_barrier(0);
       }
       if (qb > 0) rank_finish(prev, qb - 1, pb[set], wb_cur);
@@ -1001,10 +1006,16 @@ static int match_launch(sfm_ctx* h, int metric, const void* q, int64_t nq_rows, 
     // one pair at dim 128: the LDS-free kernel, with 4 query blocks per wave from 28,672 queries on and 2 below (8-20 % faster
     // than the LDS kernel at 2,000 .. 11,000 queries against 4,000 .. 50,000 train rows); the LDS kernel serves the batched
     // form, the smaller dims and the smallest pairs
-    const bool direct2 = !wg && dim == 128 && !qb4 && (double)nq_rows * (double)nt_rows >= 8e6;      // below: launch-bound, the LDS kernel's lighter pre-pass wins by ~3 us
+    // dim 256 (ORB over unpacked bits; SFM_MATCH_DIRECT256=0 keeps the LDS kernel): two query blocks per wave, eight MFMAs per step
+    const char* d256_env = getenv("SFM_MATCH_DIRECT256");
+    const bool direct256 = !wg && dim == 256 && !qb4 && (double)nq_rows * (double)nt_rows >= 8e6 && !(d256_env && d256_env[0] == '0');
+    const bool direct2 = !wg && (dim == 128 || direct256) && !qb4 && (double)nq_rows * (double)nt_rows >= 8e6;      // below: launch-bound, the LDS kernel's lighter pre-pass wins by ~3 us
     const bool direct = (qb4 || direct2) && !(d_env && d_env[0] == '0');
     if (direct)
-      hipLaunchKernelGGL(k_train_tile_u8, dim3((unsigned)((nt_rows + 31) >> 5)), dim3(256), 0, h->stream, t8, nt_rows, w.tf, w.th, w.par, w.fix_cnt);
+      {
+      if (dim == 256) hipLaunchKernelGGL(k_train_tile_u8<8>, dim3((unsigned)((nt_rows + 31) >> 5)), dim3(512), 0, h->stream, t8, nt_rows, w.tf, w.th, w.par, w.fix_cnt);
+      else hipLaunchKernelGGL(k_train_tile_u8<4>, dim3((unsigned)((nt_rows + 31) >> 5)), dim3(256), 0, h->stream, t8, nt_rows, w.tf, w.th, w.par, w.fix_cnt);
+    }
     else
       hipLaunchKernelGGL(k_train_prep_u8, dim3(cdiv((nt_rows + 1) * (dim >> 4), 256)), dim3(256), 0, h->stream, t8, nt_rows, dim, w.tf, w.th, w.par, w.fix_cnt);
     hipLaunchKernelGGL(k_row_norm_u8, dim3(cdiv(nq_rows * (dim >> 4), 256)), dim3(256), 0, h->stream, q8, nq_rows, dim, 0x7F, 0, w.qn);
@@ -1026,7 +1037,8 @@ static int match_launch(sfm_ctx* h, int metric, const void* q, int64_t nq_rows, 
         if (sscanf(we, "%d:%d", &a, &b) == 2 && a > 0 && b > 0 && a <= 1024 && b <= 1024 && nsplit > 1) { w_first = a; w_second = b; }
         else { w_first = w_second = 0; }
       }
-      if (direct2) hipLaunchKernelGGL((k_knn2_u8_direct<2>), dim3(grid), dim3(256), 0, h->stream, q8, nq_rows, w.tf, nt_rows, w.th, w.par, w.qn, nsplit, rps, w.part, w.u2, w_first, w_second);
+      if (direct256) hipLaunchKernelGGL((k_knn2_u8_direct<2, 8>), dim3(grid), dim3(256), 0, h->stream, q8, nq_rows, w.tf, nt_rows, w.th, w.par, w.qn, nsplit, rps, w.part, w.u2, w_first, w_second);
+      else if (direct2) hipLaunchKernelGGL((k_knn2_u8_direct<2>), dim3(grid), dim3(256), 0, h->stream, q8, nq_rows, w.tf, nt_rows, w.th, w.par, w.qn, nsplit, rps, w.part, w.u2, w_first, w_second);
       else hipLaunchKernelGGL((k_knn2_u8_direct<4>), dim3(grid), dim3(256), 0, h->stream, q8, nq_rows, w.tf, nt_rows, w.th, w.par, w.qn, nsplit, rps, w.part, w.u2, w_first, w_second);
     } else if (filter) {
       if (qb4) KNN_LAUNCH(4, 4, true); else if (dim == 256) KNN_LAUNCH(8, 2, true); else if (dim == 128) KNN_LAUNCH(4, 2, true); else if (dim == 64) KNN_LAUNCH(2, 2, true); else KNN_LAUNCH(1, 2, true);

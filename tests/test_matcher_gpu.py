@@ -73,10 +73,12 @@ def test_hamming_matches_oracle(gpu_ready, nq, nt):
     assert_knn_equal(gpu_knn2(b1, b2, "auto"), mo.knn2(b1, b2, "hamming"))
 
 
-@pytest.mark.parametrize("nq,nt,nbytes", [(700, 3000, 16), (4001, 6100, 32), (13000, 2500, 16), (257, 5000, 64), (2, 2, 32)])
+@pytest.mark.parametrize("nq,nt,nbytes", [(700, 3000, 16), (4001, 6100, 32), (13000, 2500, 16), (257, 5000, 64), (2, 2, 32),
+                                          (2000, 20001, 32), (300, 30017, 32)])
 def test_hamming_sizes_and_widths(gpu_ready, nq, nt, nbytes):
     """Hamming on 128 / 256 bits runs as exact uint8 L2 over the unpacked bits on the int8 kernels (k_unpack_bits; 128 bits can
-    take the LDS-free kernel, 256 bits the dim-256 instantiation, both with the candidate filter from 2,048 train rows on);
+    take the LDS-free kernel, 256 bits from 8e6 distances on its dim-256 instantiation - k_knn2_u8_direct<2, 8>: odd tile counts,
+    several train splits, a last tile of one row - and the LDS kernel below, both with the candidate filter from 2,048 train rows on);
     512 bits stay on the popcount kernel.  All against the NumPy oracle: many exact ties (distances are small integers), so
     the lowest-train-index rule decides most second neighbours."""
     from oracle import matcher_oracle as mo
