@@ -114,15 +114,51 @@ extern "C" int sfm_ba_get_layout(sfm_ba_problem p, sfm_ba_layout* out) {
 }
 
 // ------------------------------------------------------------------------------------ helpers
-__device__ __forceinline__ double wave_sum(double v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
-  return v;   // valid in lane 0
+// The same sums without a trip through LDS per step (__shfl_* is ds_bpermute: ~100 cycles each, six in a row per wave_sum - in
+// the persistent CG, one wave per SIMD, that latency is the iteration): quad permutes and row mirrors (DPP) inside a row of 16
+// lanes, v_permlane16_swap / v_permlane32_swap across rows.  Every step adds a value and its partner's in the same order on both
+// sides, so ALL lanes end with bit-identical totals.  Measured (cfg4, 20 outer iterations after 5): camera-solve slots 155 + 123
+// -> 140 + 104 us per damped solve, 310 -> 322 LM-iterations/s.
+template <int CTRL> __device__ __forceinline__ double dpp_f64(double v) {
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xF, 0xF, true);
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xF, 0xF, true);
+  return __hiloint2double(hi, lo);
 }
+// {a, b} -> (swap16: rows 1, 3 of a <-> rows 0, 2 of b; swap32: upper half of a <-> lower half of b), then a + b: with a = b = v
+// the sum of v over the two rows / halves in every lane, with two different registers one step of a halving exchange (the
+// even rows / lower half end with a's sum, the odd rows / upper half with b's)
+__device__ __forceinline__ double swap16_add(double a, double b) {
+  const auto rlo = __builtin_amdgcn_permlane16_swap((unsigned)__double2loint(a), (unsigned)__double2loint(b), false, false);
+  const auto rhi = __builtin_amdgcn_permlane16_swap((unsigned)__double2hiint(a), (unsigned)__double2hiint(b), false, false);
+  return __hiloint2double((int)rhi[0], (int)rlo[0]) + __hiloint2double((int)rhi[1], (int)rlo[1]);
+}
+__device__ __forceinline__ double swap32_add(double a, double b) {
+  const auto rlo = __builtin_amdgcn_permlane32_swap((unsigned)__double2loint(a), (unsigned)__double2loint(b), false, false);
+  const auto rhi = __builtin_amdgcn_permlane32_swap((unsigned)__double2hiint(a), (unsigned)__double2hiint(b), false, false);
+  return __hiloint2double((int)rhi[0], (int)rlo[0]) + __hiloint2double((int)rhi[1], (int)rlo[1]);
+}
+__device__ __forceinline__ double wave_sum_all(double v) {
+  v += dpp_f64<0xB1>(v);          // quad_perm [1,0,3,2]
+  v += dpp_f64<0x4E>(v);          // quad_perm [2,3,0,1]
+  v += dpp_f64<0x141>(v);         // row_half_mirror
+  v += dpp_f64<0x140>(v);         // row_mirror: every lane of a row holds the row's sum
+  v = swap16_add(v, v);           // rows 0 + 1, rows 2 + 3
+  return swap32_add(v, v);        // both halves
+}
+// (every lane gets the total; the callers that say "valid in lane 0" predate the DPP form)
+__device__ __forceinline__ double wave_sum(double v) { return wave_sum_all(v); }
 __device__ __forceinline__ double wave_max(double v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_down(v, o, 64));
   return v;
+}
+// Sum over a 256-thread block, fixed order, in every thread.  s: >= 4 doubles of LDS.
+__device__ __forceinline__ double block_sum256_fast(double v, double* s) {
+  v = wave_sum_all(v);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) s[threadIdx.x >> 6] = v;
+  __syncthreads();
+  return (s[0] + s[1]) + (s[2] + s[3]);
 }
 // Sum over a 256-thread block, fixed order; result valid in thread 0.  s: >= 4 doubles of LDS.
 __device__ __forceinline__ double block_sum256(double v, double* s) {
@@ -1797,7 +1833,7 @@ __global__ __launch_bounds__(256, 1) void k_cgs_persist(int n, double rtol2, int
     double t = 0.0;
 #pragma unroll
     for (int i = 0; i < 2 * NC; ++i) t += rv[i] * rv[i];
-    rr0 = block_sum256(t, s_red);                 // ||rhs||^2 (every thread gets it): the tolerance is relative to the right-hand side
+    rr0 = block_sum256_fast(t, s_red);                 // ||rhs||^2 (every thread gets it): the tolerance is relative to the right-hand side
   }
 
   // one round: y = S~ v for this workgroup's rows, published and gathered; returns false when the launch is abandoned
@@ -1813,7 +1849,7 @@ __global__ __launch_bounds__(256, 1) void k_cgs_persist(int n, double rtol2, int
     }
 #pragma unroll
     for (int q = 0; q < PR_ROWS; ++q) {
-      const double t = wave_sum(acc[q]);
+      const double t = wave_sum_all(acc[q]);
       if (lane == 0) s_part[q][w] = t;
     }
     __syncthreads();
@@ -1907,8 +1943,8 @@ __global__ __launch_bounds__(256, 1) void k_cgs_persist(int n, double rtol2, int
           t2 += p0 * p0 + p1 * p1;
         }
       }
-      const double dot = block_sum256(t, s_red);
-      const double pc2 = block_sum256(t2, s_red);
+      const double dot = block_sum256_fast(t, s_red);
+      const double pc2 = block_sum256_fast(t2, s_red);
       if (tid == 0) {
         const double pn2 = pc2 + f.fin_redq[n], pq = dot + f.fin_redq[n + 1];
         f.fin_sc[SFM_SC_PNORM2] = pn2; f.fin_sc[SFM_SC_PQ] = pq;
@@ -1930,7 +1966,7 @@ __global__ __launch_bounds__(256, 1) void k_cgs_persist(int n, double rtol2, int
     double t = 0.0;
 #pragma unroll
     for (int i = 0; i < 2 * NC; ++i) { pv[i] = rv[i]; t += rv[i] * rv[i]; }
-    rr = block_sum256(t, s_red);
+    rr = block_sum256_fast(t, s_red);
   }
   if (!(rr0 > 0.0)) {                               // zero right-hand side: x = 0; NaN / Inf in it: not a system CG can solve (fail 2 ->
     if (rr0 == 0.0) {                               // the caller's factorisation route reports the non-finite step)
@@ -1947,13 +1983,13 @@ __global__ __launch_bounds__(256, 1) void k_cgs_persist(int n, double rtol2, int
     double t = 0.0;
 #pragma unroll
     for (int i = 0; i < 2 * NC; ++i) t += pv[i] * yv[i];
-    const double pAp = block_sum256(t, s_red);
+    const double pAp = block_sum256_fast(t, s_red);
     if (!(pAp > 0.0)) { finish(rr, it, 1.0, 2.0); return; }       // non-positive curvature (or NaN): S~ is not positive definite
     const double a = rr / pAp;
     double t2 = 0.0;
 #pragma unroll
     for (int i = 0; i < 2 * NC; ++i) { xv[i] += a * pv[i]; rv[i] -= a * yv[i]; t2 += rv[i] * rv[i]; }
-    const double rr_new = block_sum256(t2, s_red);
+    const double rr_new = block_sum256_fast(t2, s_red);
     const double beta = rr_new / rr;
 #pragma unroll
     for (int i = 0; i < 2 * NC; ++i) pv[i] = rv[i] + beta * pv[i];
@@ -2066,38 +2102,31 @@ constexpr int SY_T = 128;
 
 // v[q] = this lane's part of the sum of row q; returns (in every lane) the sum over the 64 lanes of row (lane >> 2)
 __device__ __forceinline__ double lane_rows16_sum(double (&v)[16], int lane) {
-  {
-    const bool hi = (lane & 32) != 0;
+  // halving exchanges without LDS round trips (the ds_bpermute form of this function, 17 dependent shuffles per call, was
+  // ~0.8 us at the end of every 16-row batch of a tile): across the half-waves and across neighbouring rows by
+  // v_permlane32_swap / v_permlane16_swap, inside a row of 16 lanes by row / half-row mirrors (DPP)
+  double u[8], x[4];
 #pragma unroll
-    for (int k = 0; k < 8; ++k) {
-      const double send = hi ? v[k] : v[k + 8], keep = hi ? v[k + 8] : v[k];
-      v[k] = keep + __shfl_xor(send, 32, 64);
-    }
-  }
-  {
-    const bool hi = (lane & 16) != 0;
+  for (int k = 0; k < 8; ++k) u[k] = swap32_add(v[k], v[k + 8]);        // upper half keeps rows + 8
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const double send = hi ? v[k] : v[k + 4], keep = hi ? v[k + 4] : v[k];
-      v[k] = keep + __shfl_xor(send, 16, 64);
-    }
-  }
+  for (int k = 0; k < 4; ++k) x[k] = swap16_add(u[k], u[k + 4]);        // odd rows of 16 lanes keep rows + 4
+  double y[2];
   {
-    const bool hi = (lane & 8) != 0;
+    const bool hi = (lane & 8) != 0;                                    // lanes 8..15 of a row keep rows + 2
 #pragma unroll
     for (int k = 0; k < 2; ++k) {
-      const double send = hi ? v[k] : v[k + 2], keep = hi ? v[k + 2] : v[k];
-      v[k] = keep + __shfl_xor(send, 8, 64);
+      const double send = hi ? x[k] : x[k + 2], keep = hi ? x[k + 2] : x[k];
+      y[k] = keep + dpp_f64<0x140>(send);                               // row_mirror: lane i <-> lane 15 - i
     }
   }
   double t;
   {
-    const bool hi = (lane & 4) != 0;
-    const double send = hi ? v[0] : v[1], keep = hi ? v[1] : v[0];
-    t = keep + __shfl_xor(send, 4, 64);
+    const bool hi = (lane & 4) != 0;                                    // bit 2 keeps rows + 1
+    const double send = hi ? y[0] : y[1], keep = hi ? y[1] : y[0];
+    t = keep + dpp_f64<0x141>(send);                                    // row_half_mirror: lane i <-> lane 7 - i of its eight
   }
-  t += __shfl_xor(t, 2, 64);
-  t += __shfl_xor(t, 1, 64);
+  t += dpp_f64<0xB1>(t);                                                // the four lanes of a quad
+  t += dpp_f64<0x4E>(t);
   return t;
 }
 
@@ -2160,7 +2189,7 @@ __global__ __launch_bounds__(128) void k_cgs_big_reduce(int n, int nb, const dou
     for (int k = 0; k < nb; ++k) s += P[(size_t)k * n + i];
     Ap[i] = s;
   }
-  double d = wave_sum(i < n ? s * pvec[i] : 0.0);
+  double d = wave_sum_all(i < n ? s * pvec[i] : 0.0);
   if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = d;
   __syncthreads();
   if (threadIdx.x == 0) dots[blockIdx.x] = s_w[0] + s_w[1];
@@ -2535,7 +2564,7 @@ __global__ __launch_bounds__(64) void k_precond_invert(int C, const double* __re
 
 // Sum over a 1024-thread block, fixed order; every thread gets the result.  s: >= 17 doubles of LDS.
 __device__ __forceinline__ double block_sum1024(double v, double* s) {
-  v = wave_sum(v);
+  v = wave_sum_all(v);
   __syncthreads();
   if ((threadIdx.x & 63) == 0) s[threadIdx.x >> 6] = v;
   __syncthreads();
