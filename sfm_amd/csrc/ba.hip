@@ -904,7 +904,11 @@ __global__ __launch_bounds__(64 * SFM_SCHUR_WG_WAVES) __attribute__((amdgpu_wave
 template <int D>
 __global__ __launch_bounds__(256) void k_schur_assemble(int C, const int* __restrict__ item_ptr,
                                                         const double* __restrict__ part,
-                                                        const double* __restrict__ B, double* __restrict__ S) {
+                                                        const double* __restrict__ B, double* __restrict__ S, double* __restrict__ cg_scal) {
+  // the status words of the camera CG that follows start from zero (k_diag_einv only ever RAISES its failure word): cleared
+  // here, by the kernel that always runs before it, instead of by a memset between two kernels of the chain (a fill kernel of
+  // its own, ~5 us with its boundaries)
+  if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x < 16) cg_scal[threadIdx.x] = 0.0;
   const int c = blockIdx.x;
   const int c2 = c + blockIdx.y * 2 + (threadIdx.x >> 7);
   const int e = threadIdx.x & 127;
@@ -1461,7 +1465,8 @@ extern "C" int sfm_ba_schur_build(sfm_handle h, sfm_ba_problem p, double alpha) 
       hipLaunchKernelGGL((k_cam_reduce_chunks<DD, double, GG>), dim3((unsigned)p->n_cchunks), dim3(256), 0, h->stream, p->cch_beg,
                          p->cch_end, p->cam_obs, p->pt_idx, WS(L, G), WS(L, e), WS(L, cch_part));
     hipLaunchKernelGGL(k_schur_assemble<DD>, dim3(C, cdiv(C, 2)), dim3(256), 0, h->stream, C, p->item_ptr,
-                       WS(L, sch_part), WS(L, B), WS(L, red_S));
+                       WS(L, sch_part), WS(L, B), WS(L, red_S), WS(L, cg_scal));
+    p->cg_scal_clean = 1;
     // the chunk partials of sum_k G_k e_j came out of the diagonal-block items above (or of the pass just launched)
     hipLaunchKernelGGL(k_cam_reduce_final<DD>, dim3(cdiv(C, 4)), dim3(256), 0, h->stream, C, p->cch_ptr,
                        WS(L, cch_part), WS(L, gc), WS(L, red_S) + (size_t)n * n);
@@ -1784,7 +1789,8 @@ __global__ __launch_bounds__(256, 1) void k_cgs_persist(int n, double rtol2, int
                                                         const double* __restrict__ St, const double* __restrict__ rhs,
                                                         const double* __restrict__ x0 /* may be null: start from 0 */,
                                                         double* __restrict__ x_out, pr_u64* mail /* [2][n][2] granules */,
-                                                        pr_u64* abort_w, double* __restrict__ scal, PrFuse f, int sabotage) {
+                                                        pr_u64* abort_w, double* __restrict__ scal, PrFuse f, int sabotage,
+                                                        double* __restrict__ host_status /* pinned host memory, device-mapped: 8 words */) {
   // test hook (SFM_CGS_SABOTAGE=1): workgroup 1 never publishes, as if it had not become resident - the others must run into
   // their spin bound, post the abort word and leave; the host then takes the launch-per-iteration route
   if (sabotage > 0 && blockIdx.x == 1) return;
@@ -1903,7 +1909,13 @@ __global__ __launch_bounds__(256, 1) void k_cgs_persist(int n, double rtol2, int
     }
     if (tid == 0) {
       scal[CGS_RR0] = rr0; scal[CGS_RR] = rr; scal[CGS_ITER] = (double)it; scal[CGS_DONE] = done;
+      const double fail_now = scal[CGS_FAIL] != 0.0 ? scal[CGS_FAIL] : fail;
       if (fail != 0.0 && scal[CGS_FAIL] == 0.0) scal[CGS_FAIL] = fail;
+      // the host's copy of the verdict, written straight into its pinned page (visible when the launch has ended: an event
+      // behind the launch is all the host waits for) - a separate 64-byte device-to-host copy is a blit kernel of its own, ~4 us
+      // plus two kernel boundaries between this system and the back-substitution that waits behind it
+      host_status[CGS_RR0] = rr0; host_status[CGS_RR] = rr; host_status[CGS_ITER] = (double)it;
+      host_status[CGS_FAIL] = fail_now; host_status[CGS_DONE] = done;
     }
     const bool converged = done == 1.0 && fail == 0.0 && rr <= rtol2 * rr0;
     if (!converged || !(f.pc_out || f.fin_sc)) return;          // (workgroup-uniform)
@@ -2018,11 +2030,11 @@ static int cgs_persist_launch(sfm_ctx* h, int n, int D, const double* St, const 
   const unsigned salt = h->cgs_seq;
   const double rtol2 = rtol * rtol;
   const int sabotage = (getenv("SFM_CGS_SABOTAGE") && getenv("SFM_CGS_SABOTAGE")[0] == '1' && grid > 1) ? 1 : 0;
-#define PR_LAUNCH(NC, DD_) hipLaunchKernelGGL((k_cgs_persist<NC, DD_>), dim3(grid), dim3(256), 0, h->stream, n, rtol2, CGS_MAX_ITER, salt, St, rhs, x0_t, x_t, (pr_u64*)mail, abort_w, scal, fuse, sabotage)
+  h->pinned[pin + CGS_DONE] = -1.0;                // what a launch that never wrote its verdict reads as: abandoned
+#define PR_LAUNCH(NC, DD_) hipLaunchKernelGGL((k_cgs_persist<NC, DD_>), dim3(grid), dim3(256), 0, h->stream, n, rtol2, CGS_MAX_ITER, salt, St, rhs, x0_t, x_t, (pr_u64*)mail, abort_w, scal, fuse, sabotage, h->pinned + pin)
   if (D == 10) { if (nc <= 1) PR_LAUNCH(1, 10); else if (nc == 2) PR_LAUNCH(2, 10); else if (nc == 3) PR_LAUNCH(3, 10); else PR_LAUNCH(4, 10); }
   else { if (nc <= 1) PR_LAUNCH(1, 6); else if (nc == 2) PR_LAUNCH(2, 6); else if (nc == 3) PR_LAUNCH(3, 6); else PR_LAUNCH(4, 6); }
 #undef PR_LAUNCH
-  SFM_HIP(h, hipMemcpyAsync(h->pinned + pin, scal, 8 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
   SFM_LAUNCH_CHECK(h, "cgs_persist_launch");
   return SFM_OK;
 }
@@ -2311,7 +2323,9 @@ extern "C" int sfm_ba_schur_solve(sfm_handle h, sfm_ba_problem p, double alpha, 
   if (p->camera_solver != SFM_CAMERA_SOLVER_CHOLESKY && cgs_possible(n)) {
     // S~ = E^-1 (S + alpha I) E^-T into the factor's buffer (S stays as it is: the fallback below needs it), r~ = E^-1 r
     sfm_prof_begin(h, SFM_PROF_CHOL);
-    SFM_HIP(h, hipMemsetAsync(WS(L, cg_scal), 0, 16 * sizeof(double), h->stream));
+    // (cleared by k_schur_assemble when this solve follows its own sfm_ba_schur_build, as it does in every loop of this library)
+    if (!p->cg_scal_clean) SFM_HIP(h, hipMemsetAsync(WS(L, cg_scal), 0, 16 * sizeof(double), h->stream));
+    p->cg_scal_clean = 0;
     DISPATCH_D(D, {
       hipLaunchKernelGGL(k_diag_einv<DD>, dim3(cdiv(C, 64)), dim3(64), 0, h->stream, C, S, n, alpha, WS(L, cg_Minv), WS(L, cg_M), WS(L, cg_scal));
       hipLaunchKernelGGL(k_scale_system<DD>, dim3(C, cdiv(C, SCALE_NB)), dim3(128), 0, h->stream, n, C, S, alpha, WS(L, cg_Minv), dw.Lm);
