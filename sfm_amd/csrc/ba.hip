@@ -536,7 +536,7 @@ __global__ __launch_bounds__(256) void k_lin_finalize(int n, int D, const double
 
 __global__ __launch_bounds__(256) void k_finish_linearize(int n, const double* __restrict__ red_lin,
                                                           const double* __restrict__ gmax,
-                                                          double* __restrict__ sc) {
+                                                          double* __restrict__ sc, double* __restrict__ hsc) {
   __shared__ double s_red[4];
   double g2 = 0.0, gm = 0.0, hm = 0.0;
   for (int i = threadIdx.x; i < n; i += 256) {
@@ -547,10 +547,10 @@ __global__ __launch_bounds__(256) void k_finish_linearize(int n, const double* _
   double gmt = block_max256(gm, s_red);
   double hmt = block_max256(hm, s_red);
   if (threadIdx.x == 0) {
-    sc[SFM_SC_COST] = red_lin[n];
-    sc[SFM_SC_GNORM2] = g2t + red_lin[n + 1];
-    sc[SFM_SC_GINF] = fmax(gmt, gmax[0]);
-    sc[SFM_SC_HDIAG] = fmax(hmt, gmax[1]);
+    sc[SFM_SC_COST] = hsc[SFM_SC_COST] = red_lin[n];
+    sc[SFM_SC_GNORM2] = hsc[SFM_SC_GNORM2] = g2t + red_lin[n + 1];
+    sc[SFM_SC_GINF] = hsc[SFM_SC_GINF] = fmax(gmt, gmax[0]);
+    sc[SFM_SC_HDIAG] = hsc[SFM_SC_HDIAG] = fmax(hmt, gmax[1]);
   }
 }
 
@@ -1086,7 +1086,7 @@ __global__ void k_add_vec(const double* __restrict__ a, const double* __restrict
 __global__ __launch_bounds__(256) void k_finish_solve(int n, const double* __restrict__ pc,
                                                       const double* __restrict__ red_q,
                                                       const double* __restrict__ y, int want_q,
-                                                      const int* __restrict__ flag, double* __restrict__ sc) {
+                                                      const int* __restrict__ flag, double* __restrict__ sc, double* __restrict__ hsc) {
   __shared__ double s_red[4];
   double a = 0.0, b = 0.0;
   for (int i = threadIdx.x; i < n; i += 256) {
@@ -1097,12 +1097,12 @@ __global__ __launch_bounds__(256) void k_finish_solve(int n, const double* __res
   double bt = block_sum256(b, s_red);
   if (threadIdx.x == 0) {
     const double pn2 = at + red_q[n], pq = want_q ? (bt + red_q[n + 1]) : 0.0;
-    sc[SFM_SC_PNORM2] = pn2;
-    sc[SFM_SC_PQ] = pq;
+    sc[SFM_SC_PNORM2] = hsc[SFM_SC_PNORM2] = pn2;
+    sc[SFM_SC_PQ] = hsc[SFM_SC_PQ] = pq;
     // 1: non-positive pivot, 2: a triangular solve stalled, 3: the step is not finite (NaN/Inf in the system)
     int f = *flag;
     if (f == 0 && !(isfinite(pn2) && isfinite(pq))) f = 3;
-    sc[SFM_SC_CHOL_FAIL] = (double)f;
+    sc[SFM_SC_CHOL_FAIL] = hsc[SFM_SC_CHOL_FAIL] = (double)f;
   }
 }
 
@@ -1236,7 +1236,7 @@ __global__ __launch_bounds__(256) void k_step_finalize(const double* __restrict_
 __global__ __launch_bounds__(256) void k_finish_step(int n_c, const double* __restrict__ pc, double scale,
                                                      const double* __restrict__ x_new,
                                                      const double* __restrict__ red_step,
-                                                     double* __restrict__ sc) {
+                                                     double* __restrict__ sc, double* __restrict__ hsc) {
   __shared__ double s_red[4];
   double s2 = 0.0, x2 = 0.0;
   for (int i = threadIdx.x; i < n_c; i += 256) {
@@ -1247,8 +1247,9 @@ __global__ __launch_bounds__(256) void k_finish_step(int n_c, const double* __re
   double a = block_sum256(s2, s_red);
   double b = block_sum256(x2, s_red);
   if (threadIdx.x == 0) {
-    sc[SFM_SC_JS2] = red_step[0]; sc[SFM_SC_GTS] = red_step[1]; sc[SFM_SC_COST_NEW] = red_step[2];
-    sc[SFM_SC_SNORM2] = a + red_step[3]; sc[SFM_SC_XNEW_NORM2] = b + red_step[4];
+    sc[SFM_SC_JS2] = hsc[SFM_SC_JS2] = red_step[0]; sc[SFM_SC_GTS] = hsc[SFM_SC_GTS] = red_step[1];
+    sc[SFM_SC_COST_NEW] = hsc[SFM_SC_COST_NEW] = red_step[2];
+    sc[SFM_SC_SNORM2] = hsc[SFM_SC_SNORM2] = a + red_step[3]; sc[SFM_SC_XNEW_NORM2] = hsc[SFM_SC_XNEW_NORM2] = b + red_step[4];
   }
 }
 
@@ -1426,7 +1427,7 @@ extern "C" int sfm_ba_finish_linearize(sfm_handle h, sfm_ba_problem p) {
   Lay L; int rc = check_problem(h, p, &L); if (rc) return rc;
   double* ws = (double*)p->workspace;
   hipLaunchKernelGGL(k_finish_linearize, dim3(1), dim3(256), 0, h->stream, p->n_cams * p->cam_dim,
-                     WS(L, red_lin), WS(L, gmax), WS(L, scalars));
+                     WS(L, red_lin), WS(L, gmax), WS(L, scalars), p->host_sc);
   SFM_LAUNCH_CHECK(h, "sfm_ba_finish_linearize");
   return SFM_OK;
 }
@@ -1536,7 +1537,8 @@ __device__ __forceinline__ bool small_chol_inverse(double (&L)[D][D], double (&X
 // (defined with the implicit-Schur PCG further down)
 __global__ void k_dot(int n, const double* __restrict__ a, const double* __restrict__ b, double* __restrict__ out);
 __global__ void k_finish_solve_pcg(int n, const double* __restrict__ pc, const double* __restrict__ red_q, int want_q,
-                                   const double* __restrict__ dotp, const double* __restrict__ failp, double* __restrict__ sc);
+                                   const double* __restrict__ dotp, const double* __restrict__ failp, double* __restrict__ sc,
+                                   double* __restrict__ hsc);
 
 // ------------------------------------------------------------------------------------ CG on the explicit reduced system
 // Once S has been formed (and, multi-rank, all-reduced) the replicated camera solve is a latency chain in the dense
@@ -1782,6 +1784,7 @@ struct PrFuse {
   const double* fin_pc;    // non-null (q system): the scalars of the damped solve are finished here on convergence
   const double* fin_redq;  //   [n + 2]: ... | sum ||p_p||^2 | sum ||v||^2
   double* fin_sc;          //   SFM_SC_PNORM2, SFM_SC_PQ, SFM_SC_CHOL_FAIL
+  double* fin_hsc;         //   the same three in the problem's pinned host mirror of the scalars (sfm_ba_read_scalars)
 };
 
 template <int NC, int D>
@@ -1959,10 +1962,10 @@ __global__ __launch_bounds__(256, 1) void k_cgs_persist(int n, double rtol2, int
       const double pc2 = block_sum256_fast(t2, s_red);
       if (tid == 0) {
         const double pn2 = pc2 + f.fin_redq[n], pq = dot + f.fin_redq[n + 1];
-        f.fin_sc[SFM_SC_PNORM2] = pn2; f.fin_sc[SFM_SC_PQ] = pq;
+        f.fin_sc[SFM_SC_PNORM2] = f.fin_hsc[SFM_SC_PNORM2] = pn2; f.fin_sc[SFM_SC_PQ] = f.fin_hsc[SFM_SC_PQ] = pq;
         double fl = scal[CGS_FAIL] != 0.0 ? 1.0 : 0.0;
         if (fl == 0.0 && !(isfinite(pn2) && isfinite(pq))) fl = 3.0;
-        f.fin_sc[SFM_SC_CHOL_FAIL] = fl;
+        f.fin_sc[SFM_SC_CHOL_FAIL] = f.fin_hsc[SFM_SC_CHOL_FAIL] = fl;
       }
     }
   };
@@ -2351,7 +2354,7 @@ extern "C" int sfm_ba_schur_solve(sfm_handle h, sfm_ba_problem p, double alpha, 
       // (converged / fall back) but must not idle the GPU for it: the status words are copied to pinned memory, an event is
       // recorded behind the copy, the back-substitution is enqueued on the assumption that the solve converged (it does: 0
       // fallbacks in the bench schedules), and only then the host waits - for the event, not for the stream.
-      PrFuse fuse = {WS(L, cg_Minv), nullptr, WS(L, pc), nullptr, nullptr, nullptr};
+      PrFuse fuse = {WS(L, cg_Minv), nullptr, WS(L, pc), nullptr, nullptr, nullptr, nullptr};
       rc = cgs_persist_launch(h, n, D, dw.Lm, S + (size_t)n * n, x0, WS(L, cg_z), WS(L, cg_mail), WS(L, cg_scal), CGS_RTOL, fuse, SFM_PIN_CG1);
       if (rc) return rc;
       SFM_HIP(h, hipEventRecord(h->cg_event, h->stream));
@@ -2425,7 +2428,7 @@ static int finish_solve_by_factor(sfm_ctx* h, sfm_ba_problem p, const Lay& L, do
     sfm_prof_end(h, SFM_PROF_TRSV);
   }
   hipLaunchKernelGGL(k_finish_solve, dim3(1), dim3(256), 0, h->stream, n, WS(L, pc), WS(L, red_q), WS(L, y),
-                     want_q, (const int*)dw.flag, WS(L, scalars));
+                     want_q, (const int*)dw.flag, WS(L, scalars), p->host_sc);
   SFM_LAUNCH_CHECK(h, "sfm_ba_finish_solve");
   return SFM_OK;
 }
@@ -2449,7 +2452,7 @@ extern "C" int sfm_ba_finish_solve(sfm_handle h, sfm_ba_problem p, int want_q) {
         // ONE persistent launch: r~2 = E^-1 (p_c + rhs2 pieces) in its prologue, r~2 . x~2 and the scalars of the solve in its
         // epilogue.  Its verdict travels to pinned memory with the copy enqueued behind it and is looked at where the host
         // synchronises anyway: in sfm_ba_read_scalars, which redoes this step from the factorisation if it has to.
-        PrFuse fuse = {WS(L, cg_Minv), WS(L, red_q), nullptr, WS(L, pc), WS(L, red_q), WS(L, scalars)};
+        PrFuse fuse = {WS(L, cg_Minv), WS(L, red_q), nullptr, WS(L, pc), WS(L, red_q), WS(L, scalars), p->host_sc};
         rc = cgs_persist_launch(h, n, D, dw.Lm, WS(L, pc), nullptr, WS(L, cg_z), WS(L, cg_mail), WS(L, cg_scal), CGS_RTOL, fuse, SFM_PIN_CG2);
         if (rc) return rc;
         if (!warm_on) {
@@ -2482,7 +2485,7 @@ extern "C" int sfm_ba_finish_solve(sfm_handle h, sfm_ba_problem p, int want_q) {
     }
     if (status == 0) {
       hipLaunchKernelGGL(k_finish_solve_pcg, dim3(1), dim3(256), 0, h->stream, n, WS(L, pc), WS(L, red_q), want_q, WS(L, cg_scal) + 8,
-                         WS(L, cg_scal) + CGS_FAIL, WS(L, scalars));
+                         WS(L, cg_scal) + CGS_FAIL, WS(L, scalars), p->host_sc);
       SFM_LAUNCH_CHECK(h, "sfm_ba_finish_solve");
       return SFM_OK;
     }
@@ -2654,17 +2657,17 @@ __global__ __launch_bounds__(1024) void k_dot(int n, const double* __restrict__ 
 // scalars after a PCG solve: PNORM2 = ||p_c||^2 + sum ||p_p||^2, PQ = rhs2^T S^-1 rhs2 + sum ||v||^2, failure code
 __global__ __launch_bounds__(256) void k_finish_solve_pcg(int n, const double* __restrict__ pc, const double* __restrict__ red_q,
                                                           int want_q, const double* __restrict__ dotp, const double* __restrict__ failp,
-                                                          double* __restrict__ sc) {
+                                                          double* __restrict__ sc, double* __restrict__ hsc) {
   __shared__ double s_red[4];
   double a = 0.0;
   for (int i = threadIdx.x; i < n; i += 256) a += pc[i] * pc[i];
   const double at = block_sum256(a, s_red);
   if (threadIdx.x == 0) {
     const double pn2 = at + red_q[n], pq = want_q ? (*dotp + red_q[n + 1]) : 0.0;
-    sc[SFM_SC_PNORM2] = pn2; sc[SFM_SC_PQ] = pq;
+    sc[SFM_SC_PNORM2] = hsc[SFM_SC_PNORM2] = pn2; sc[SFM_SC_PQ] = hsc[SFM_SC_PQ] = pq;
     double f = *failp != 0.0 ? 1.0 : 0.0;                   // 1: a block or S itself is not positive definite
     if (f == 0.0 && !(isfinite(pn2) && isfinite(pq))) f = 3.0;
-    sc[SFM_SC_CHOL_FAIL] = f;
+    sc[SFM_SC_CHOL_FAIL] = hsc[SFM_SC_CHOL_FAIL] = f;
   }
 }
 
@@ -2830,7 +2833,7 @@ extern "C" int sfm_ba_solve_pcg(sfm_handle h, sfm_ba_problem p, double alpha, in
     sfm_prof_end(h, SFM_PROF_TRSV);
   }
   hipLaunchKernelGGL(k_finish_solve_pcg, dim3(1), dim3(256), 0, h->stream, n, WS(L, pc), WS(L, red_q), want_q, WS(L, cg_scal) + CG_DOT,
-                     WS(L, cg_scal) + CG_FAIL, WS(L, scalars));
+                     WS(L, cg_scal) + CG_FAIL, WS(L, scalars), p->host_sc);
   SFM_LAUNCH_CHECK(h, "sfm_ba_solve_pcg");
   if (iters_host) *iters_host = cg.iters;
   return SFM_OK;
@@ -2863,7 +2866,7 @@ extern "C" int sfm_ba_finish_step(sfm_handle h, sfm_ba_problem p, const double* 
   double* ws = (double*)p->workspace;
   (void)x;
   hipLaunchKernelGGL(k_finish_step, dim3(1), dim3(256), 0, h->stream, p->n_cams * p->cam_dim, WS(L, pc), scale,
-                     x_new, WS(L, red_step), WS(L, scalars));
+                     x_new, WS(L, red_step), WS(L, scalars), p->host_sc);
   SFM_LAUNCH_CHECK(h, "sfm_ba_finish_step");
   return SFM_OK;
 }
@@ -2877,12 +2880,12 @@ __global__ __launch_bounds__(256) void k_sq_partials(int64_t n, const double* __
   if (threadIdx.x == 0) part[blockIdx.x] = a;
 }
 __global__ __launch_bounds__(256) void k_xnorm_finish(int n_c, const double* __restrict__ x, const double* __restrict__ red_step,
-                                                      double* __restrict__ sc) {
+                                                      double* __restrict__ sc, double* __restrict__ hsc) {
   __shared__ double s_red[4];
   double a = 0.0;
   for (int i = threadIdx.x; i < n_c; i += 256) a += x[i] * x[i];
   const double t = block_sum256(a, s_red);
-  if (threadIdx.x == 0) sc[SFM_SC_XNEW_NORM2] = t + red_step[4];
+  if (threadIdx.x == 0) sc[SFM_SC_XNEW_NORM2] = hsc[SFM_SC_XNEW_NORM2] = t + red_step[4];
 }
 int ba_xnorm_partial(sfm_ctx* h, sfm_ba_problem p, const double* x) {
   Lay L; int rc = check_problem(h, p, &L); if (rc) return rc;
@@ -2897,7 +2900,7 @@ int ba_xnorm_partial(sfm_ctx* h, sfm_ba_problem p, const double* x) {
 int ba_xnorm_finish(sfm_ctx* h, sfm_ba_problem p, const double* x) {
   Lay L; int rc = check_problem(h, p, &L); if (rc) return rc;
   double* ws = (double*)p->workspace;
-  hipLaunchKernelGGL(k_xnorm_finish, dim3(1), dim3(256), 0, h->stream, p->n_cams * p->cam_dim, x, WS(L, red_step), WS(L, scalars));
+  hipLaunchKernelGGL(k_xnorm_finish, dim3(1), dim3(256), 0, h->stream, p->n_cams * p->cam_dim, x, WS(L, red_step), WS(L, scalars), p->host_sc);
   SFM_LAUNCH_CHECK(h, "ba_xnorm_finish");
   return SFM_OK;
 }
@@ -2905,7 +2908,9 @@ int ba_xnorm_finish(sfm_ctx* h, sfm_ba_problem p, const double* x) {
 extern "C" int sfm_ba_read_scalars(sfm_handle h, sfm_ba_problem p, double* out_host) {
   Lay L; int rc = check_problem(h, p, &L); if (rc) return rc;
   double* ws = (double*)p->workspace;
-  SFM_HIP(h, hipMemcpyAsync(h->pinned, WS(L, scalars), SFM_SC_COUNT * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  // every kernel that writes one of the scalars writes it into the problem's pinned host mirror too (p->host_sc): waiting for
+  // the stream is all that is left to do here - the 128-byte device-to-host copy was a blit kernel of its own in front of every
+  // one of these waits
   SFM_HIP(h, hipStreamSynchronize(h->stream));
   if (p->cg2_pending) {
     // the verdict of the persistent CG on the second system of the last damped solve (sfm_ba_finish_solve) arrived with this
@@ -2916,11 +2921,10 @@ extern "C" int sfm_ba_read_scalars(sfm_handle h, sfm_ba_problem p, double* out_h
     cgs_persist_status(h, SFM_PIN_CG2, &p->cg_iters, &status, &ran);
     if (!(ran && status == 0)) {
       if ((rc = finish_solve_by_factor(h, p, L, ws, 1, true))) return rc;
-      SFM_HIP(h, hipMemcpyAsync(h->pinned, WS(L, scalars), SFM_SC_COUNT * sizeof(double), hipMemcpyDeviceToHost, h->stream));
       SFM_HIP(h, hipStreamSynchronize(h->stream));
     }
   }
-  memcpy(out_host, h->pinned, SFM_SC_COUNT * sizeof(double));
+  memcpy(out_host, p->host_sc, SFM_SC_COUNT * sizeof(double));
   return SFM_OK;
 }
 

@@ -35,6 +35,7 @@ struct sfm_ba_prob {
   // factor's buffer), 0 = from the factorisation
   int camera_solver, cg_state, cg_iters, cg_fallbacks;
   int cg2_pending;           // the persistent CG of the second system is in flight: sfm_ba_read_scalars looks at its verdict
+  double* host_sc;           // pinned host mirror of the SFM_SC_* scalars (written by the kernels that write them; sfm_ba_read_scalars)
   int cg_scal_clean;         // k_schur_assemble has just cleared the CG status words (sfm_ba_schur_solve then skips its memset)
   // 1: some camera appears more than once on a track.  The diagonal Schur blocks then hold cross pairs besides the
   // self-pairs, so k_schur_items must not take its fused diagonal path (one gather for both operands, right-hand side in

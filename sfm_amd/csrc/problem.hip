@@ -168,6 +168,7 @@ extern "C" void sfm_ba_destroy_problem(sfm_ba_problem p) {
   for (void* q : owned)
     if (q) (void)hipFree(q);
   if (p->owns_workspace && p->workspace) (void)hipFree(p->workspace);
+  if (p->host_sc) (void)hipHostFree(p->host_sc);
   delete p;
 }
 
@@ -193,6 +194,12 @@ extern "C" int sfm_ba_create_problem(sfm_handle h, const sfm_ba_desc* d, sfm_ba_
   p->h = h;
   p->n_cams = C; p->n_pts = P; p->cam_dim = d->cam_dim; p->apply_reg = d->apply_reg; p->precision = d->precision;
   p->camera_solver = d->camera_solver;
+  // pinned host mirror of the scalars (every kernel that writes one writes it here too: sfm_ba_read_scalars only waits)
+  if (hipHostMalloc((void**)&p->host_sc, SFM_SC_COUNT * sizeof(double), hipHostMallocDefault) != hipSuccess) {
+    p->host_sc = nullptr; sfm_ba_destroy_problem(p);
+    return sfm_fail(h, SFM_ERR_HIP, "sfm_ba_create_problem", "pinned host memory for the scalars");
+  }
+  memset(p->host_sc, 0, SFM_SC_COUNT * sizeof(double));
   p->n_obs = N;
   p->fx0 = d->fx0; p->fy0 = d->fy0; p->cx0 = d->cx0; p->cy0 = d->cy0;
   p->width = d->width; p->height = d->height; p->reg_weight = d->reg_weight;
