@@ -1874,12 +1874,26 @@ __global__ __launch_bounds__(256, 1) void k_cgs_persist(int n, double rtol2, int
     bool ok = false;
     for (unsigned spins = 0; spins < PR_SPIN_LIMIT; ++spins) {
       pr_u64 g[4 * NC];
+      // a thread's four granules of a chunk (two doubles) are 32 contiguous, 32-byte aligned bytes: TWO 16-byte device-scope loads
+      // instead of four 8-byte ones (8-byte accesses run at 0.54-0.70 of the 16-byte rate, MI355X_MICROARCH.md).  Every 8-byte
+      // half carries its own tag, so a 16-byte load that saw its two halves at different times is still read correctly.  The
+      // compiler does not see these loads: the wait below is theirs.
+      typedef unsigned pr_u32x4 __attribute__((ext_vector_type(4)));
+      pr_u32x4 q[2 * NC];
 #pragma unroll
       for (int c = 0; c < NC; ++c) {
         const int col = 2 * tid + 512 * c;
         const pr_u64* gp = slot + 2 * (size_t)(col < n ? col : 0);
+        asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(q[2 * c]) : "v"(gp) : "memory");
+        asm volatile("global_load_dwordx4 %0, %1, off offset:16 sc1" : "=v"(q[2 * c + 1]) : "v"(gp) : "memory");
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
-        for (int i = 0; i < 4; ++i) g[4 * c + i] = __hip_atomic_load(gp + i, PR_RLX_AGENT);
+      for (int c = 0; c < 2 * NC; ++c) {
+        // (the wait must sit between the loads and the first use of ANY of their registers: tie them to it)
+        asm volatile("" : "+v"(q[c]));
+        g[2 * c] = (pr_u64)q[c].x | ((pr_u64)q[c].y << 32);
+        g[2 * c + 1] = (pr_u64)q[c].z | ((pr_u64)q[c].w << 32);
       }
       bool all = true;
 #pragma unroll
