@@ -1867,8 +1867,11 @@ __global__ __launch_bounds__(256, 1) void k_cgs_persist(int n, double rtol2, int
     if (tid < PR_ROWS && row0 + tid < n) {
       const double y = (s_part[tid][0] + s_part[tid][1]) + (s_part[tid][2] + s_part[tid][3]);
       const pr_u64 bits = (pr_u64)__double_as_longlong(y);
-      __hip_atomic_store(slot + 2 * (size_t)(row0 + tid), ((pr_u64)tag << 32) | (bits & 0xFFFFFFFFull), PR_RLX_AGENT);
-      __hip_atomic_store(slot + 2 * (size_t)(row0 + tid) + 1, ((pr_u64)tag << 32) | (bits >> 32), PR_RLX_AGENT);
+      // the two granules of the entry in ONE 16-byte device-scope store (the workgroup's eight entries = one whole 128-byte line
+      // from one instruction); each 8-byte half carries its own tag, so the store need not be atomic as a whole
+      typedef unsigned pr_st4 __attribute__((ext_vector_type(4)));
+      const pr_st4 pk = {(unsigned)(bits & 0xFFFFFFFFull), tag, (unsigned)(bits >> 32), tag};
+      asm volatile("global_store_dwordx4 %0, %1, off sc1" :: "v"(slot + 2 * (size_t)(row0 + tid)), "v"(pk) : "memory");
     }
     // gather this thread's columns: 4 granules per chunk (two doubles), re-read until every tag matches
     bool ok = false;
