@@ -527,6 +527,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((QB == 2 &&
   // the bounds of a wave's QB x 32 queries are kept query-in-block major ([l31][qb]: this kernel is their only user), so
   // that a lane fetches its QB values with QB / 2 eight-byte loads; lanes past the last query read values nobody posts
   const int* u2_mine = u2g + q0 + l31 * QB;
+  const __amdgpu_buffer_rsrc_t u2_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)u2g, 0, 0x7FFFFFFF, 0x00020000);
 #pragma unroll
   for (int qb = 0; qb < QB; ++qb) {
     const int64_t qi = q0 + qb * 32 + l31;
@@ -661,11 +662,20 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((QB == 2 &&
     const int pb_prev = pb[pset];                          // the previous tile's parity word, before its set is refilled
     // the bounds the other splits have posted: fetched in EVERY tile (same number of loads on every path, see below), past
     // the XCD's own L2 (device-scope load), used from the next tile on
+    if (QB == 4) {
+      // the lane's four bounds are 16 contiguous, 16-byte aligned bytes: ONE device-scope load (a buffer load with sc1, which the
+      // compiler counts like the others) instead of two 8-byte ones
+#pragma unroll
+      for (int qb = 0; qb < QB; ++qb) u2_seen[qb] = u2_next[qb];
+      const v4i v = __builtin_amdgcn_raw_buffer_load_b128(u2_rsrc, (int)((q0 + (int64_t)l31 * QB) * 4), 0, 16);
+      u2_next[0] = v[0]; u2_next[1] = v[1]; u2_next[2 % QB] = v[2]; u2_next[3 % QB] = v[3];
+    } else {
 #pragma unroll
     for (int qb = 0; qb < QB; qb += 2) {
       u2_seen[qb] = u2_next[qb]; u2_seen[qb + 1] = u2_next[qb + 1];
       const unsigned long long v = __hip_atomic_load((const unsigned long long*)(u2_mine + qb), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       u2_next[qb] = (int)(unsigned)v; u2_next[qb + 1] = (int)(unsigned)(v >> 32);
+    }
     }
     load_tile(tile0 + (t + 1 < n_tiles ? t + 1 : t), pset);
     const int wb_prev = (((t - 1) & 7) << 5) | (4 * half), wb_cur = ((t & 7) << 5) | (4 * half);
