@@ -1590,11 +1590,20 @@ __global__ __launch_bounds__(64) void k_diag_einv(int C, const double* __restric
 constexpr int SCALE_NB = 8;
 template <int D>
 __global__ __launch_bounds__(128) void k_scale_system(int n, int C, const double* __restrict__ S, double alpha,
-                                                      const double* __restrict__ Einv, double* __restrict__ St) {
+                                                      const double* __restrict__ Einv, double* __restrict__ St,
+                                                      const double* __restrict__ rhs, double* __restrict__ rhs_t) {
   __shared__ double sB[SCALE_NB][D * D], sT[SCALE_NB][D * D], sE2[SCALE_NB][D * D], sE1[D * D];
   const int c = blockIdx.x, e = threadIdx.x;
   const int a = e / D, b = e - a * D;
   const int c2_0 = blockIdx.y * SCALE_NB;
+  // rhs~_c = E_c^-1 rhs_c for the CG that follows (the first workgroup of the block row does it, once for everybody: the
+  // persistent kernel used to form all of rhs~ in every one of its workgroups)
+  if (rhs_t && blockIdx.y == 0 && e < D) {
+    double t = 0.0;
+#pragma unroll
+    for (int k = 0; k < D; ++k) t += Einv[(size_t)c * D * D + e * D + k] * rhs[c * D + k];     // E^-1 lower: stored zeros above
+    rhs_t[c * D + e] = t;
+  }
   if (c2_0 + SCALE_NB <= c) return;                      // (workgroup-uniform) nothing at or right of the diagonal here
   const int nb = (C - c2_0) < SCALE_NB ? (C - c2_0) : SCALE_NB;
   if (e < D * D) {
@@ -1637,14 +1646,14 @@ __global__ __launch_bounds__(128) void k_scale_system(int n, int C, const double
 // out_c = Einv_c v_c (transpose 0) or Einv_c^T v_c (transpose 1), optionally negated
 template <int D>
 __global__ void k_block_mv(int C, const double* __restrict__ Einv, const double* __restrict__ v, double* __restrict__ out,
-                           int transpose, double sgn) {
+                           int transpose, double sgn, const double* __restrict__ v2 = nullptr /* added to v when given */) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= C * D) return;
   const int c = i / D, a = i - c * D;
   const double* E = Einv + (size_t)c * D * D;
   double t = 0.0;
 #pragma unroll
-  for (int k = 0; k < D; ++k) t += (transpose ? E[k * D + a] : E[a * D + k]) * v[c * D + k];
+  for (int k = 0; k < D; ++k) t += (transpose ? E[k * D + a] : E[a * D + k]) * (v[c * D + k] + (v2 ? v2[c * D + k] : 0.0));
   out[i] = sgn * t;
 }
 // out = a - delta * b (b may be null)
@@ -1785,6 +1794,9 @@ struct PrFuse {
   const double* fin_redq;  //   [n + 2]: ... | sum ||p_p||^2 | sum ||v||^2
   double* fin_sc;          //   SFM_SC_PNORM2, SFM_SC_PQ, SFM_SC_CHOL_FAIL
   double* fin_hsc;         //   the same three in the problem's pinned host mirror of the scalars (sfm_ba_read_scalars)
+  int rhs_scaled;          // 1: `rhs` is rhs~ already (k_scale_system / k_block_mv formed it; Einv then only serves the epilogue).  Forming
+                           //    it in the prologue - every workgroup all n entries, ~200 eight-byte loads per thread - took 17-19 us per
+                           //    launch by in-kernel stamps, more than seven iterations
 };
 
 template <int NC, int D>
@@ -1817,7 +1829,7 @@ __global__ __launch_bounds__(256, 1) void k_cgs_persist(int n, double rtol2, int
   for (int c = 0; c < NC; ++c) {
     const int col = 2 * tid + 512 * c;
     const bool in = col < n;
-    if (f.Einv) {
+    if (f.Einv && !f.rhs_scaled) {
       // rhs~_i = sum_k E^-1[cam][a][k] (rhs + rhs_b)[cam D + k]   (E^-1 lower triangular: the stored zeros above cost nothing here)
 #pragma unroll
       for (int u = 0; u < 2; ++u) {
@@ -2348,7 +2360,8 @@ extern "C" int sfm_ba_schur_solve(sfm_handle h, sfm_ba_problem p, double alpha, 
     p->cg_scal_clean = 0;
     DISPATCH_D(D, {
       hipLaunchKernelGGL(k_diag_einv<DD>, dim3(cdiv(C, 64)), dim3(64), 0, h->stream, C, S, n, alpha, WS(L, cg_Minv), WS(L, cg_M), WS(L, cg_scal));
-      hipLaunchKernelGGL(k_scale_system<DD>, dim3(C, cdiv(C, SCALE_NB)), dim3(128), 0, h->stream, n, C, S, alpha, WS(L, cg_Minv), dw.Lm);
+      hipLaunchKernelGGL(k_scale_system<DD>, dim3(C, cdiv(C, SCALE_NB)), dim3(128), 0, h->stream, n, C, S, alpha, WS(L, cg_Minv), dw.Lm,
+                         S + (size_t)n * n, WS(L, cg_r));
     });
     int status = 1, ran = 0;
     // Warm start (persistent kernel only; SFM_CGS_WARM=1, off by default: measured 13 % fewer iterations and no time saved).
@@ -2371,8 +2384,8 @@ extern "C" int sfm_ba_schur_solve(sfm_handle h, sfm_ba_problem p, double alpha, 
       // (converged / fall back) but must not idle the GPU for it: the status words are copied to pinned memory, an event is
       // recorded behind the copy, the back-substitution is enqueued on the assumption that the solve converged (it does: 0
       // fallbacks in the bench schedules), and only then the host waits - for the event, not for the stream.
-      PrFuse fuse = {WS(L, cg_Minv), nullptr, WS(L, pc), nullptr, nullptr, nullptr, nullptr};
-      rc = cgs_persist_launch(h, n, D, dw.Lm, S + (size_t)n * n, x0, WS(L, cg_z), WS(L, cg_mail), WS(L, cg_scal), CGS_RTOL, fuse, SFM_PIN_CG1);
+      PrFuse fuse = {WS(L, cg_Minv), nullptr, WS(L, pc), nullptr, nullptr, nullptr, nullptr, 1};      // rhs~ = cg_r (k_scale_system)
+      rc = cgs_persist_launch(h, n, D, dw.Lm, WS(L, cg_r), x0, WS(L, cg_z), WS(L, cg_mail), WS(L, cg_scal), CGS_RTOL, fuse, SFM_PIN_CG1);
       if (rc) return rc;
       SFM_HIP(h, hipEventRecord(h->cg_event, h->stream));
       sfm_prof_end(h, SFM_PROF_CHOL);
@@ -2469,8 +2482,11 @@ extern "C" int sfm_ba_finish_solve(sfm_handle h, sfm_ba_problem p, int want_q) {
         // ONE persistent launch: r~2 = E^-1 (p_c + rhs2 pieces) in its prologue, r~2 . x~2 and the scalars of the solve in its
         // epilogue.  Its verdict travels to pinned memory with the copy enqueued behind it and is looked at where the host
         // synchronises anyway: in sfm_ba_read_scalars, which redoes this step from the factorisation if it has to.
-        PrFuse fuse = {WS(L, cg_Minv), WS(L, red_q), nullptr, WS(L, pc), WS(L, red_q), WS(L, scalars), p->host_sc};
-        rc = cgs_persist_launch(h, n, D, dw.Lm, WS(L, pc), nullptr, WS(L, cg_z), WS(L, cg_mail), WS(L, cg_scal), CGS_RTOL, fuse, SFM_PIN_CG2);
+        // rhs~2 = E^-1 (p_c + rhs2 pieces) by one small launch (in the CG kernel's prologue every workgroup formed all of it)
+        DISPATCH_D(D, hipLaunchKernelGGL(k_block_mv<DD>, dim3(cdiv(n, 256)), dim3(256), 0, h->stream, C, WS(L, cg_Minv), WS(L, pc),
+                                         WS(L, cg_r), 0, 1.0, WS(L, red_q)));
+        PrFuse fuse = {WS(L, cg_Minv), nullptr, nullptr, WS(L, pc), WS(L, red_q), WS(L, scalars), p->host_sc, 1};
+        rc = cgs_persist_launch(h, n, D, dw.Lm, WS(L, cg_r), nullptr, WS(L, cg_z), WS(L, cg_mail), WS(L, cg_scal), CGS_RTOL, fuse, SFM_PIN_CG2);
         if (rc) return rc;
         if (!warm_on) {
           p->cg2_pending = 1;
