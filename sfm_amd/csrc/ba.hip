@@ -904,11 +904,23 @@ __global__ __launch_bounds__(64 * SFM_SCHUR_WG_WAVES) __attribute__((amdgpu_wave
 template <int D>
 __global__ __launch_bounds__(256) void k_schur_assemble(int C, const int* __restrict__ item_ptr,
                                                         const double* __restrict__ part,
-                                                        const double* __restrict__ B, double* __restrict__ S, double* __restrict__ cg_scal) {
+                                                        const double* __restrict__ B, double* __restrict__ S, double* __restrict__ cg_scal,
+                                                        const int* __restrict__ cch_ptr, const double* __restrict__ cch_part,
+                                                        const double* __restrict__ gc, double* __restrict__ rhs_out) {
   // the status words of the camera CG that follows start from zero (k_diag_einv only ever RAISES its failure word): cleared
   // here, by the kernel that always runs before it, instead of by a memset between two kernels of the chain (a fill kernel of
   // its own, ~5 us with its boundaries)
   if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x < 16) cg_scal[threadIdx.x] = 0.0;
+  // ... and the right-hand side r_c = g_c - sum over the camera's chunk partials of sum_k G_k e_j (they came out of the
+  // diagonal-block items, or of the camera-wise pass): the first workgroup of a block row adds them up, four slots of chunks
+  // side by side as k_cam_reduce_final does - that kernel was a launch of its own here (4.8 us plus a boundary)
+  if (blockIdx.y == 0 && threadIdx.x < 64) {
+    const int cc = blockIdx.x, lane = threadIdx.x, sl = lane >> 4, a = lane & 15;
+    double t = 0.0;
+    for (int ch = cch_ptr[cc] + sl; ch < cch_ptr[cc + 1]; ch += 4) t += cch_part[(size_t)ch * 16 + a];
+    const double t1 = __shfl(t, a + 16, 64), t2 = __shfl(t, a + 32, 64), t3 = __shfl(t, a + 48, 64);
+    if (sl == 0 && a < D) rhs_out[cc * D + a] = gc[cc * D + a] - ((t + t1) + (t2 + t3));
+  }
   const int c = blockIdx.x;
   const int c2 = c + blockIdx.y * 2 + (threadIdx.x >> 7);
   const int e = threadIdx.x & 127;
@@ -974,7 +986,21 @@ __global__ __launch_bounds__(256) void k_cam_reduce_chunks(const int* __restrict
 // entry walked all 20 (11 us per call for 2,000 numbers, twice per damped solve).
 template <int D>
 __global__ __launch_bounds__(256) void k_cam_reduce_final(int C, const int* __restrict__ cch_ptr, const double* __restrict__ part,
-                                                          const double* __restrict__ base, double* __restrict__ out) {
+                                                          const double* __restrict__ base, double* __restrict__ out,
+                                                          const double* __restrict__ sum_part = nullptr, int sum_nblk = 0, int sum_cnt = 0,
+                                                          double* __restrict__ sum_dst = nullptr) {
+  // (one workgroup more than the cameras need, when asked: the sums of another kernel's per-block partials - k_sum_partials as a
+  // launch of its own was 4.6 us plus a kernel boundary in the chain of every damped solve)
+  if (sum_part && blockIdx.x == gridDim.x - 1) {
+    __shared__ double s_red[4];
+    for (int q = 0; q < sum_cnt; ++q) {
+      double t = 0.0;
+      for (int i = threadIdx.x; i < sum_nblk; i += 256) t += sum_part[(size_t)i * sum_cnt + q];
+      const double tt = block_sum256(t, s_red);
+      if (threadIdx.x == 0) sum_dst[q] = tt;
+    }
+    return;
+  }
   const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (c >= C) return;
   const int lane = threadIdx.x & 63, s = lane >> 4, a = lane & 15;
@@ -1466,11 +1492,9 @@ extern "C" int sfm_ba_schur_build(sfm_handle h, sfm_ba_problem p, double alpha) 
       hipLaunchKernelGGL((k_cam_reduce_chunks<DD, double, GG>), dim3((unsigned)p->n_cchunks), dim3(256), 0, h->stream, p->cch_beg,
                          p->cch_end, p->cam_obs, p->pt_idx, WS(L, G), WS(L, e), WS(L, cch_part));
     hipLaunchKernelGGL(k_schur_assemble<DD>, dim3(C, cdiv(C, 2)), dim3(256), 0, h->stream, C, p->item_ptr,
-                       WS(L, sch_part), WS(L, B), WS(L, red_S), WS(L, cg_scal));
+                       WS(L, sch_part), WS(L, B), WS(L, red_S), WS(L, cg_scal), p->cch_ptr, WS(L, cch_part), WS(L, gc),
+                       WS(L, red_S) + (size_t)n * n);
     p->cg_scal_clean = 1;
-    // the chunk partials of sum_k G_k e_j came out of the diagonal-block items above (or of the pass just launched)
-    hipLaunchKernelGGL(k_cam_reduce_final<DD>, dim3(cdiv(C, 4)), dim3(256), 0, h->stream, C, p->cch_ptr,
-                       WS(L, cch_part), WS(L, gc), WS(L, red_S) + (size_t)n * n);
     sfm_prof_end(h, SFM_PROF_SCHUR);
   });
   SFM_LAUNCH_CHECK(h, "sfm_ba_schur_build");
@@ -2329,16 +2353,18 @@ static void launch_backsub(sfm_ctx* h, sfm_ba_problem p, const Lay& L, double* w
                                                   p->cam_idx, WS(L, G), WS(L, pc), WS(L, tmp3)));
   hipLaunchKernelGGL(k_backsub, dim3((unsigned)L.nblk_pt), dim3(256), 0, h->stream, P, p->pt_ptr, WS(L, tmp3),
                      WS(L, Linv), WS(L, e), WS(L, pp), WS(L, v), WS(L, part_pt));
-  hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(256), 0, h->stream, WS(L, part_pt), (int)L.nblk_pt, 2,
-                     WS(L, red_q) + n);
   if (want_q) {
     DISPATCH_DT(D, p->precision, {
       if (p->n_cchunks > 0)
         hipLaunchKernelGGL((k_cam_reduce_chunks<DD, double, GG>), dim3((unsigned)p->n_cchunks), dim3(256), 0, h->stream, p->cch_beg,
                            p->cch_end, p->cam_obs, p->pt_idx, WS(L, G), WS(L, v), WS(L, cch_part));
-      hipLaunchKernelGGL(k_cam_reduce_final<DD>, dim3(cdiv(C, 4)), dim3(256), 0, h->stream, C, p->cch_ptr,
-                         WS(L, cch_part), (const double*)nullptr, WS(L, red_q));
+      // (+ 1 workgroup: the two sums over the point pass's per-block partials, sum ||p_p||^2 and sum ||v||^2)
+      hipLaunchKernelGGL(k_cam_reduce_final<DD>, dim3(cdiv(C, 4) + 1), dim3(256), 0, h->stream, C, p->cch_ptr,
+                         WS(L, cch_part), (const double*)nullptr, WS(L, red_q), WS(L, part_pt), (int)L.nblk_pt, 2, WS(L, red_q) + n);
     });
+  } else {
+    hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(256), 0, h->stream, WS(L, part_pt), (int)L.nblk_pt, 2,
+                       WS(L, red_q) + n);
   }
   sfm_prof_end(h, SFM_PROF_BACKSUB);
 }
