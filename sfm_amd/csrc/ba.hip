@@ -926,14 +926,21 @@ __global__ __launch_bounds__(256) void k_schur_assemble(int C, const int* __rest
   const int e = threadIdx.x & 127;
   if (c2 >= C || e >= D * D) return;
   const int64_t blk = (int64_t)c * C - (int64_t)c * (c - 1) / 2 + (c2 - c);
-  double s = 0.0;
-  for (int it = item_ptr[blk]; it < item_ptr[blk + 1]; ++it) s += part[(size_t)it * (D * D) + e];
   const int rr = e / D, col = e - rr * D;
+  // the thread also sums the TRANSPOSED element (col, rr): it then writes the mirror block's entry (rr, col), so that both blocks
+  // leave as 80-byte row segments (from the element's own thread the mirror was 100 scattered 8-byte stores per block: worth
+  // 70 us of 420 at 1000 cameras, nothing measurable at 200)
+  const int eT = col * D + rr;
+  double s = 0.0, sT = 0.0;
+  for (int it = item_ptr[blk]; it < item_ptr[blk + 1]; ++it) {
+    s += part[(size_t)it * (D * D) + e];
+    sT += part[(size_t)it * (D * D) + eT];
+  }
   double v = -s;
   if (c == c2) v += B[(size_t)c * D * D + e];
   const int n = C * D;
   S[(size_t)(c * D + rr) * n + c2 * D + col] = v;
-  if (c != c2) S[(size_t)(c2 * D + col) * n + c * D + rr] = v;
+  if (c != c2) S[(size_t)(c2 * D + rr) * n + c * D + col] = -sT;
 }
 
 // out[c][a] = (base ? base[c][a] : 0) - sum_{k in camera c} sum_m G_k[m][a] vec[pt(k)][m]
