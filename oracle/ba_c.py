@@ -5,13 +5,13 @@ import numpy as np
 
 from . import build_c
 
-_lib = None
+_libs = {}
 
 
-def lib():
-    global _lib
-    if _lib is None:
-        l = C.CDLL(build_c.build())
+def lib(variant=None):
+    """The compiled restatement; variant="reverse_sums" is the same source with another summation order (build_c.VARIANTS)."""
+    if variant not in _libs:
+        l = C.CDLL(build_c.build(variant=variant))
         vp, i32, i64, f64 = C.c_void_p, C.c_int, C.c_int64, C.c_double
         l.bao_create.restype = vp
         l.bao_create.argtypes = [i32, i32, i32, i64, vp, vp, vp, vp, f64, f64, f64, i32]
@@ -37,8 +37,8 @@ def lib():
             avail = os.cpu_count() or 1
         l.bao_set_threads(max(1, min(avail, int(os.environ.get("SFM_ORACLE_THREADS", "16")))))
         l.mo_knn2_u8.argtypes = [vp, i64, vp, i64, i32, vp, vp, vp, vp]
-        _lib = l
-    return _lib
+        _libs[variant] = l
+    return _libs[variant]
 
 
 def _p(a):
@@ -49,8 +49,8 @@ class CBA:
     """C oracle instance for one problem (arrays as in oracle.ba_oracle.BAProblem)."""
 
     def __init__(self, n_cams, n_pts, d, cam_idx, pt_idx, uv, K0, width=1024.0, height=768.0, reg_weight=0.1,
-                 apply_reg=True):
-        self.l = lib()
+                 apply_reg=True, variant=None):
+        self.l = lib(variant)
         self.ci = np.ascontiguousarray(cam_idx, dtype=np.int32)
         self.pi = np.ascontiguousarray(pt_idx, dtype=np.int32)
         self.uv = np.ascontiguousarray(uv, dtype=np.float64)

@@ -40,6 +40,14 @@ typedef struct {
   int n;
 } bao;
 
+/* Sensitivity probe (tools/diag/oracle_rounding_sensitivity.py): -DBAO_REVERSE_SUMS walks every camera's observation list
+   backwards in the sums B_c, g_c and in the rows of S - the same arithmetic in another, equally legitimate summation order. */
+#ifdef BAO_REVERSE_SUMS
+#define BAO_ORDER(i, lo, hi) ((lo) + (hi) - 1 - (i))
+#else
+#define BAO_ORDER(i, lo, hi) (i)
+#endif
+
 static void rod(const double* r, double* R, double* dR) {
   double th2 = r[0] * r[0] + r[1] * r[1] + r[2] * r[2], a, b, a1, b1;
   if (th2 < 1e-4) {
@@ -182,7 +190,8 @@ void bao_linearize(bao* b, const double* x) {
   for (int c = 0; c < C; ++c) {
     double* Bc = b->B + (size_t)c * d * d; double* g = b->gc + (size_t)c * d;
     memset(Bc, 0, (size_t)d * d * 8); memset(g, 0, d * 8);
-    for (int i = b->cam_ptr[c]; i < b->cam_ptr[c + 1]; ++i) {
+    for (int i0 = b->cam_ptr[c]; i0 < b->cam_ptr[c + 1]; ++i0) {
+      const int i = BAO_ORDER(i0, b->cam_ptr[c], b->cam_ptr[c + 1]);
       const int k = b->cam_obs[i];
       const double* j = b->Jc + (size_t)k * 2 * d; const double f0 = b->ft[2 * k], f1 = b->ft[2 * k + 1];
       for (int a = 0; a < d; ++a) {
@@ -285,7 +294,8 @@ int bao_solve(bao* b, double alpha, int want_q, double* pnorm, double* pq) {
     memset(Sr, 0, (size_t)d * n * 8);
     for (int a = 0; a < d; ++a) { for (int q = 0; q < d; ++q) Sr[(size_t)a * n + c * d + q] = b->B[(size_t)c * d * d + a * d + q]; Sr[(size_t)a * n + c * d + a] += alpha; }
     double* r = b->r + (size_t)c * d; memcpy(r, b->gc + (size_t)c * d, d * 8);
-    for (int i = b->cam_ptr[c]; i < b->cam_ptr[c + 1]; ++i) {
+    for (int i0 = b->cam_ptr[c]; i0 < b->cam_ptr[c + 1]; ++i0) {
+      const int i = BAO_ORDER(i0, b->cam_ptr[c], b->cam_ptr[c + 1]);
       const int k = b->cam_obs[i], j = b->pt_idx[k];
       const double *G = b->G + (size_t)k * 3 * d, *e = b->e + (size_t)j * 3;
       for (int a = 0; a < d; ++a) r[a] -= G[a] * e[0] + G[d + a] * e[1] + G[2 * d + a] * e[2];

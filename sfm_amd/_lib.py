@@ -211,6 +211,18 @@ class Handle:
 _handles = {}
 
 
+def _release_handles():
+    """At interpreter exit: the per-device handles go LAST, after a collection has finalised every problem / loop state that is
+    still alive (a failed test keeps its frame, and with it a backend, until the very end)."""
+    import gc
+    gc.collect()
+    _handles.clear()
+
+
+import atexit
+atexit.register(_release_handles)
+
+
 def get_handle(device=0):
     h = _handles.get(device)
     if h is None:

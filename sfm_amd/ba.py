@@ -5,6 +5,7 @@ from __future__ import annotations
 
 import ctypes as C
 import math
+import weakref
 
 import numpy as np
 
@@ -102,13 +103,23 @@ class GpuBA:
         self._sc = (C.c_double * _lib.SC_COUNT)()
         self.n_solves = 0
         self._reduce_cb = None
+        self._open_trf = weakref.WeakSet()
+
+    def close(self):
+        """Release the problem.  Loop states begun on it are ended first: when a cycle (a kept traceback, say) is collected the
+        finalizers of backend and loop state run in no particular order, and sfm_ba_trf_end on a destroyed problem - or
+        sfm_ba_destroy_problem on a destroyed handle - is a use after free."""
+        for st in list(getattr(self, "_open_trf", ())):
+            st.close()
+        if getattr(self, "_pp", None):
+            if self.h._h:                      # the handle outlives its problems unless the interpreter is tearing down
+                self.h.lib.sfm_synchronize(self.h._h)
+                self.h.lib.sfm_ba_destroy_problem(self._pp)
+            self._pp = _lib.vp()
 
     def __del__(self):
         try:
-            if self._pp:
-                self.h.lib.sfm_synchronize(self.h._h)
-                self.h.lib.sfm_ba_destroy_problem(self._pp)
-                self._pp = _lib.vp()
+            self.close()
         except Exception:
             pass
 
@@ -302,6 +313,7 @@ class CTrf:
         self._fn, self._keep, user = be._reduce_hook()
         self._st = _lib.vp()
         be.h.call("sfm_ba_trf_begin", be._pp, C.c_void_p(be.x.data_ptr()), C.byref(o), self._fn, user, C.byref(self._st))
+        be._open_trf.add(self)
 
     def outer(self):
         more = C.c_int(0)
@@ -322,9 +334,11 @@ class CTrf:
         return TRFResult(r.cost, r.nfev, r.njev, r.status, r.optimality, r.n_solves, trace)
 
     def close(self):
-        if self._st:
-            self.be.h.lib.sfm_ba_trf_end(self._st)
+        if getattr(self, "_st", None):
+            if self.be._pp and self.be.h._h:   # never after the problem or the handle is gone (GpuBA.close ends us first)
+                self.be.h.lib.sfm_ba_trf_end(self._st)
             self._st = _lib.vp()
+            self.be._open_trf.discard(self)
 
     def __del__(self):
         try:
