@@ -292,6 +292,14 @@ int sfm_ba_finish_step(sfm_handle h, sfm_ba_problem p, const double* x, double s
  * there - its verdict arrives with this synchronisation, and if it did not converge the q term is redone from the
  * factorisation here (no exchange between ranks is involved).  Read the scalars through this call, not from the workspace. */
 int sfm_ba_read_scalars(sfm_handle h, sfm_ba_problem p, double* out_host);
+/* Tell the library that this problem is ONE RANK'S SHARD of a multi-rank solve (points sharded, cameras replicated: SURVEY.md
+ * section 8e; the reference has no counterpart - its solve is single-process, /root/reference/utils/sfm_reconstruction.py:506-514).
+ * Every rank must then take the same route through the replicated camera solve, because the routes sum in different orders:
+ * a persistent-CG launch that had to be abandoned on one rank is launched again instead of being replaced by the
+ * launch-per-iteration route on that rank alone, and if it cannot run the solve fails with SFM_ERR_HIP (set SFM_CGS_PERSIST=0
+ * on all ranks).  Implied by a non-null reduce hook in sfm_ba_trf_begin / sfm_ba_run_trf / sfm_ba_solve_pcg; a host that
+ * drives the stages itself and reduces between them calls this once after sfm_ba_create_problem. */
+int sfm_ba_set_sharded(sfm_handle h, sfm_ba_problem p, int sharded);
 /* SFM_CAMERA_SOLVER_CG bookkeeping since the problem was created: CG iterations spent, solves that fell back. */
 int sfm_ba_solver_stats(sfm_ba_problem p, int64_t* cg_iters_host, int64_t* cg_fallbacks_host);
 

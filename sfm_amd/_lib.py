@@ -92,6 +92,7 @@ SIGNATURES = {
     "sfm_ba_destroy_problem": (None, [vp]),
     "sfm_ba_get_structure": (C.c_int, [vp, C.POINTER(BAStructureView)]),
     "sfm_ba_get_layout": (C.c_int, [vp, C.POINTER(BALayout)]),
+    "sfm_ba_set_sharded": (C.c_int, [vp, vp, C.c_int]),
     "sfm_ba_solver_stats": (C.c_int, [vp, C.POINTER(i64), C.POINTER(i64)]),
     "sfm_ba_pcg_stats": (C.c_int, [vp, C.POINTER(i64), C.POINTER(f64)]),
     "sfm_ba_bind_workspace": (C.c_int, [vp, vp, vp, i64]),

@@ -94,6 +94,8 @@ class GpuBA:
         self.lay = lay
         self.ws = torch.zeros(lay.total_bytes, dtype=torch.uint8, device=self.dev)
         self.h.call("sfm_ba_bind_workspace", self._pp, C.c_void_p(self.ws.data_ptr()), lay.total_bytes)
+        if self.comm.world_size > 1:           # one rank's shard: the camera solve must take the same route on every rank
+            self.h.call("sfm_ba_set_sharded", self._pp, 1)
         sv = _lib.BAStructureView()
         self.h.lib.sfm_ba_get_structure(self._pp, C.byref(sv))
         self.sview = sv

@@ -61,6 +61,7 @@ class RcclComm:
         from . import _lib
         self._lib = _lib
         self.h = _lib.get_handle(device)
+        self.group = group
         if rank is None or world_size is None:
             import torch.distributed as dist
             if dist.is_available() and dist.is_initialized():
@@ -97,7 +98,8 @@ class RcclComm:
             pass
 
     def _reduce(self, t, op):
-        if not t.is_cuda or t.dtype.itemsize != 8 or not t.is_contiguous():
+        import torch
+        if not t.is_cuda or t.dtype != torch.float64 or not t.is_contiguous():
             raise ValueError("RcclComm reduces contiguous float64 CUDA tensors in place")
         self.h.call("sfm_comm_allreduce", C.c_void_p(t.data_ptr()), t.numel(), op)
         return t
@@ -118,5 +120,5 @@ class RcclComm:
             return [obj]
         import torch.distributed as dist
         out = [None] * self.world_size
-        dist.all_gather_object(out, obj)
+        dist.all_gather_object(out, obj, group=self.group)
         return out

@@ -22,6 +22,8 @@
 #include <cstdlib>
 #include <type_traits>
 #include <cmath>
+#include <atomic>
+#include <chrono>
 
 typedef double v4d __attribute__((ext_vector_type(4)));
 
@@ -2075,7 +2077,7 @@ __global__ __launch_bounds__(256, 1) void k_cgs_persist(int n, double rtol2, int
 
 // One persistent launch for a system (k_cgs_persist), in two halves so that the host never idles the GPU on its status:
 // cgs_persist_launch enqueues the kernel and the copy of its 8 status words into pinned memory (slot pin: SFM_PIN_CG1 /
-// SFM_PIN_CG2) and returns false when the kernel is not usable here (n, handle state, SFM_CGS_PERSIST=0);
+// the problem's own slot for the second system) and returns false when the kernel is not usable here (n, handle state, SFM_CGS_PERSIST=0);
 // cgs_persist_status interprets the copy once the caller knows it has arrived (an event behind it, or a later stream
 // synchronisation).  *ran = 0: the launch was abandoned - the caller takes the launch-per-iteration route (cgs_solve) with its
 // separate pre / post kernels; *status = 0: converged (and whatever `fuse` asked for has been done by workgroup 0).
@@ -2083,35 +2085,66 @@ static bool cgs_persist_usable(sfm_ctx* h, int n) {
   const char* e = getenv("SFM_CGS_PERSIST");       // looked at per solve (a test switches it): "0" = one launch per iteration
   return n <= PR_MAX_N && (n & 1) == 0 && !h->cgs_persist_off && !(e && e[0] == '0');
 }
+// The salt of a launch's granule tags comes from ONE process-wide counter (24 bits, never 0 = what cleared memory reads as),
+// started from the clock: a handle that is destroyed and created again, or two handles sharing a workspace over time, can never
+// replay a salt whose granules still sit in a mailbox (a per-handle counter restarting at 1 could: the reader would then take
+// stale entries for fresh ones - silently).  sfm_ba_bind_workspace clears the mailbox of a caller-owned workspace besides.
+static unsigned cgs_next_salt() {
+  static std::atomic<unsigned> seq{(unsigned)(std::chrono::steady_clock::now().time_since_epoch().count() >> 10)};
+  unsigned s;
+  do { s = (seq.fetch_add(1u, std::memory_order_relaxed) + 1u) & 0xFFFFFFu; } while (s == 0u);
+  return s;
+}
 static int cgs_persist_launch(sfm_ctx* h, int n, int D, const double* St, const double* rhs, const double* x0_t, double* x_t, double* mail,
-                              double* scal, double rtol, const PrFuse& fuse, int pin) {
+                              double* scal, double rtol, const PrFuse& fuse, double* pin) {
   const unsigned grid = (unsigned)cdiv(n, PR_ROWS);
   const int nc = (int)cdiv(n, 512);
   pr_u64* abort_w = (pr_u64*)(scal + 12);
-  h->cgs_seq = (h->cgs_seq + 1u) & 0xFFFFFFu;
-  if (h->cgs_seq == 0u) h->cgs_seq = 1u;           // tag 0 is what zeroed memory reads as
-  const unsigned salt = h->cgs_seq;
+  const unsigned salt = cgs_next_salt();
   const double rtol2 = rtol * rtol;
   const int sabotage = (getenv("SFM_CGS_SABOTAGE") && getenv("SFM_CGS_SABOTAGE")[0] == '1' && grid > 1) ? 1 : 0;
-  h->pinned[pin + CGS_DONE] = -1.0;                // what a launch that never wrote its verdict reads as: abandoned
-#define PR_LAUNCH(NC, DD_) hipLaunchKernelGGL((k_cgs_persist<NC, DD_>), dim3(grid), dim3(256), 0, h->stream, n, rtol2, CGS_MAX_ITER, salt, St, rhs, x0_t, x_t, (pr_u64*)mail, abort_w, scal, fuse, sabotage, h->pinned + pin)
+  pin[CGS_DONE] = -1.0;                            // what a launch that never wrote its verdict reads as: abandoned
+#define PR_LAUNCH(NC, DD_) hipLaunchKernelGGL((k_cgs_persist<NC, DD_>), dim3(grid), dim3(256), 0, h->stream, n, rtol2, CGS_MAX_ITER, salt, St, rhs, x0_t, x_t, (pr_u64*)mail, abort_w, scal, fuse, sabotage, pin)
   if (D == 10) { if (nc <= 1) PR_LAUNCH(1, 10); else if (nc == 2) PR_LAUNCH(2, 10); else if (nc == 3) PR_LAUNCH(3, 10); else PR_LAUNCH(4, 10); }
   else { if (nc <= 1) PR_LAUNCH(1, 6); else if (nc == 2) PR_LAUNCH(2, 6); else if (nc == 3) PR_LAUNCH(3, 6); else PR_LAUNCH(4, 6); }
 #undef PR_LAUNCH
   SFM_LAUNCH_CHECK(h, "cgs_persist_launch");
   return SFM_OK;
 }
-static void cgs_persist_status(sfm_ctx* h, int pin, int* iters_out, int* status, int* ran) {
-  const double* st = h->pinned + pin;
+// `sharded`: the problem is one rank's shard.  Every rank must then take the SAME route through the camera solve - the routes
+// sum in different orders, so a rank that switched on its own would hold a replicated camera step that differs from its
+// peers' in the last bits, and with it, sooner or later, a different trial history and a different sequence of collectives.
+// An abandoned launch is therefore neither replaced by the launch-per-iteration route nor remembered on the handle there:
+// the caller launches the persistent kernel again (cgs_persist_retry) and, if that fails too, the solve fails loudly.
+static void cgs_persist_status(sfm_ctx* h, const double* st, int sharded, int* iters_out, int* status, int* ran) {
   *ran = 0; *status = 1;
   if (st[CGS_DONE] == -1.0) {                       // the launch was abandoned (a spin ran out)
-    h->cgs_persist_off = 1;
-    fprintf(stderr, "sfm_amd: the persistent CG launch was abandoned (grid not co-resident?); using one launch per iteration from now on\n");
+    if (!sharded) {
+      h->cgs_persist_off = 1;
+      fprintf(stderr, "sfm_amd: the persistent CG launch was abandoned (grid not co-resident?); using one launch per iteration from now on\n");
+    }
     return;
   }
   *ran = 1;
   *iters_out += (int)st[CGS_ITER];
   if (st[CGS_FAIL] == 0.0 && st[CGS_DONE] != 0.0) *status = 0;
+}
+constexpr int CGS_SHARDED_RETRIES = 3;
+// sharded problems only: launch the same system again (fresh salt), wait for it, up to CGS_SHARDED_RETRIES times
+static int cgs_persist_retry(sfm_ctx* h, int n, int D, const double* St, const double* rhs, const double* x0_t, double* x_t, double* mail,
+                             double* scal, double rtol, const PrFuse& fuse, double* pin, int* iters_out, int* status, int* ran) {
+  for (int attempt = 1; attempt <= CGS_SHARDED_RETRIES && !*ran; ++attempt) {
+    fprintf(stderr, "sfm_amd: the persistent CG launch of a sharded solve was abandoned; launching it again (%d of %d)\n", attempt, CGS_SHARDED_RETRIES);
+    SFM_HIP(h, hipMemsetAsync(scal, 0, 16 * sizeof(double), h->stream));
+    int rc = cgs_persist_launch(h, n, D, St, rhs, x0_t, x_t, mail, scal, rtol, fuse, pin); if (rc) return rc;
+    SFM_HIP(h, hipStreamSynchronize(h->stream));
+    cgs_persist_status(h, pin, 1, iters_out, status, ran);
+  }
+  if (!*ran)
+    return sfm_fail(h, SFM_ERR_HIP, "camera CG",
+                    "the persistent kernel could not run on this rank (its grid was not co-resident) and a sharded solve must take the "
+                    "same route on every rank: set SFM_CGS_PERSIST=0 on ALL ranks");
+  return SFM_OK;
 }
 
 // x~ = S~^-1 rhs~ by CG, one launch per iteration (k_cgs_iter); returns 0 converged / 1 not converged or broken (caller falls
@@ -2376,6 +2409,13 @@ static void launch_backsub(sfm_ctx* h, sfm_ba_problem p, const Lay& L, double* w
   sfm_prof_end(h, SFM_PROF_BACKSUB);
 }
 
+extern "C" int sfm_ba_set_sharded(sfm_handle h, sfm_ba_problem p, int sharded) {
+  if (!h) return SFM_ERR_ARG;
+  if (!p) return sfm_fail(h, SFM_ERR_ARG, "sfm_ba_set_sharded", "null problem");
+  p->sharded = sharded ? 1 : 0;
+  return SFM_OK;
+}
+
 extern "C" int sfm_ba_schur_solve(sfm_handle h, sfm_ba_problem p, double alpha, int want_q) {
   Lay L; int rc = check_problem(h, p, &L); if (rc) return rc;
   double* ws = (double*)p->workspace;
@@ -2418,13 +2458,19 @@ extern "C" int sfm_ba_schur_solve(sfm_handle h, sfm_ba_problem p, double alpha, 
       // recorded behind the copy, the back-substitution is enqueued on the assumption that the solve converged (it does: 0
       // fallbacks in the bench schedules), and only then the host waits - for the event, not for the stream.
       PrFuse fuse = {WS(L, cg_Minv), nullptr, WS(L, pc), nullptr, nullptr, nullptr, nullptr, 1};      // rhs~ = cg_r (k_scale_system)
-      rc = cgs_persist_launch(h, n, D, dw.Lm, WS(L, cg_r), x0, WS(L, cg_z), WS(L, cg_mail), WS(L, cg_scal), CGS_RTOL, fuse, SFM_PIN_CG1);
+      rc = cgs_persist_launch(h, n, D, dw.Lm, WS(L, cg_r), x0, WS(L, cg_z), WS(L, cg_mail), WS(L, cg_scal), CGS_RTOL, fuse, h->pinned + SFM_PIN_CG1);
       if (rc) return rc;
       SFM_HIP(h, hipEventRecord(h->cg_event, h->stream));
       sfm_prof_end(h, SFM_PROF_CHOL);
       launch_backsub(h, p, L, ws, want_q);
       SFM_HIP(h, hipEventSynchronize(h->cg_event));
-      cgs_persist_status(h, SFM_PIN_CG1, &p->cg_iters, &status, &ran);
+      cgs_persist_status(h, h->pinned + SFM_PIN_CG1, p->sharded, &p->cg_iters, &status, &ran);
+      if (!ran && p->sharded) {                       // never switch routes on one rank alone: the same kernel again, then the back-substitution again
+        rc = cgs_persist_retry(h, n, D, dw.Lm, WS(L, cg_r), x0, WS(L, cg_z), WS(L, cg_mail), WS(L, cg_scal), CGS_RTOL, fuse, h->pinned + SFM_PIN_CG1,
+                               &p->cg_iters, &status, &ran);
+        if (rc) return rc;
+        if (status == 0) launch_backsub(h, p, L, ws, want_q);
+      }
       if (ran && status == 0) {
         if (warm_on) {
           SFM_HIP(h, hipMemcpyAsync(warm, WS(L, pc), (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
@@ -2519,7 +2565,7 @@ extern "C" int sfm_ba_finish_solve(sfm_handle h, sfm_ba_problem p, int want_q) {
         DISPATCH_D(D, hipLaunchKernelGGL(k_block_mv<DD>, dim3(cdiv(n, 256)), dim3(256), 0, h->stream, C, WS(L, cg_Minv), WS(L, pc),
                                          WS(L, cg_r), 0, 1.0, WS(L, red_q)));
         PrFuse fuse = {WS(L, cg_Minv), nullptr, nullptr, WS(L, pc), WS(L, red_q), WS(L, scalars), p->host_sc, 1};
-        rc = cgs_persist_launch(h, n, D, dw.Lm, WS(L, cg_r), nullptr, WS(L, cg_z), WS(L, cg_mail), WS(L, cg_scal), CGS_RTOL, fuse, SFM_PIN_CG2);
+        rc = cgs_persist_launch(h, n, D, dw.Lm, WS(L, cg_r), nullptr, WS(L, cg_z), WS(L, cg_mail), WS(L, cg_scal), CGS_RTOL, fuse, p->host_sc + SFM_SC_COUNT);
         if (rc) return rc;
         if (!warm_on) {
           p->cg2_pending = 1;
@@ -2527,7 +2573,12 @@ extern "C" int sfm_ba_finish_solve(sfm_handle h, sfm_ba_problem p, int want_q) {
           return SFM_OK;
         }
         SFM_HIP(h, hipStreamSynchronize(h->stream));
-        cgs_persist_status(h, SFM_PIN_CG2, &p->cg_iters, &status, &ran);
+        cgs_persist_status(h, p->host_sc + SFM_SC_COUNT, p->sharded, &p->cg_iters, &status, &ran);
+        if (!ran && p->sharded) {
+          rc = cgs_persist_retry(h, n, D, dw.Lm, WS(L, cg_r), nullptr, WS(L, cg_z), WS(L, cg_mail), WS(L, cg_scal), CGS_RTOL, fuse,
+                                 p->host_sc + SFM_SC_COUNT, &p->cg_iters, &status, &ran);
+          if (rc) return rc;
+        }
         if (ran && status == 0) {
           if (p->warm_pc_ok) {                       // q_c = E^-T x~_2 = -dp_c/dalpha for the next system's start vector
             DISPATCH_D(D, hipLaunchKernelGGL(k_block_mv<DD>, dim3(cdiv(n, 256)), dim3(256), 0, h->stream, C, WS(L, cg_Minv), WS(L, cg_z),
@@ -2833,6 +2884,7 @@ extern "C" int sfm_ba_solve_pcg(sfm_handle h, sfm_ba_problem p, double alpha, in
   const int C = p->n_cams, P = p->n_pts, D = p->cam_dim, n = C * D;
   const int64_t N = p->n_obs;
   Pcg cg{h, p, L, ws, alpha, rtol, max_iter, reduce, reduce_user, 0};
+  if (reduce) p->sharded = 1;          // the formed-S fallback below solves a replicated camera system: same route on every rank
   SFM_HIP(h, hipMemsetAsync(WS(L, cg_scal), 0, 16 * sizeof(double), h->stream));
   // point factors, G, and this rank's part of the right-hand side r = g_c - W C_a^-1 g_p and of the diagonal blocks
   sfm_prof_begin(h, SFM_PROF_BUILD_G);
@@ -2984,7 +3036,16 @@ extern "C" int sfm_ba_read_scalars(sfm_handle h, sfm_ba_problem p, double* out_h
     // factorisation now (no exchange between ranks is involved: red_q has been reduced already)
     p->cg2_pending = 0;
     int status = 1, ran = 0;
-    cgs_persist_status(h, SFM_PIN_CG2, &p->cg_iters, &status, &ran);
+    cgs_persist_status(h, p->host_sc + SFM_SC_COUNT, p->sharded, &p->cg_iters, &status, &ran);
+    if (!ran && p->sharded) {
+      // a sharded solve: the same kernel again (same inputs: r~2 is still in cg_r, S~ in the factor's buffer), never another route
+      const int C = p->n_cams, D = p->cam_dim, n = C * D;
+      DenseWs dw; dense_ws_carve(WS(L, dense), n, &dw);
+      PrFuse fuse = {WS(L, cg_Minv), nullptr, nullptr, WS(L, pc), WS(L, red_q), WS(L, scalars), p->host_sc, 1};
+      rc = cgs_persist_retry(h, n, D, dw.Lm, WS(L, cg_r), nullptr, WS(L, cg_z), WS(L, cg_mail), WS(L, cg_scal), CGS_RTOL, fuse,
+                             p->host_sc + SFM_SC_COUNT, &p->cg_iters, &status, &ran);
+      if (rc) return rc;
+    }
     if (!(ran && status == 0)) {
       if ((rc = finish_solve_by_factor(h, p, L, ws, 1, true))) return rc;
       SFM_HIP(h, hipStreamSynchronize(h->stream));

@@ -35,7 +35,11 @@ struct sfm_ba_prob {
   // factor's buffer), 0 = from the factorisation
   int camera_solver, cg_state, cg_iters, cg_fallbacks;
   int cg2_pending;           // the persistent CG of the second system is in flight: sfm_ba_read_scalars looks at its verdict
-  double* host_sc;           // pinned host mirror of the SFM_SC_* scalars (written by the kernels that write them; sfm_ba_read_scalars)
+  double* host_sc;           // pinned host mirror of the SFM_SC_* scalars (written by the kernels that write them; sfm_ba_read_scalars),
+                             // followed by the 8 status words of THIS problem's pending second-system CG (a slot per problem: two
+                             // problems on one handle may both have a verdict in flight between finish_solve and read_scalars)
+  int sharded;               // this problem is one rank's shard of a multi-rank solve (sfm_ba_set_sharded, or a reduce hook given to
+                             // the loop / sfm_ba_solve_pcg): a route whose choice could differ between ranks is never switched locally
   int cg_scal_clean;         // k_schur_assemble has just cleared the CG status words (sfm_ba_schur_solve then skips its memset)
   // 1: some camera appears more than once on a track.  The diagonal Schur blocks then hold cross pairs besides the
   // self-pairs, so k_schur_items must not take its fused diagonal path (one gather for both operands, right-hand side in

@@ -6,6 +6,7 @@
 // One communicator per handle = per (process, device); every rank calls the same sequence of stages, so the collectives
 // line up by construction.  Reductions are in place, float64, SUM or MAX.
 #include <dlfcn.h>
+#include <mutex>
 #include "ba_internal.h"
 
 namespace {
@@ -22,31 +23,41 @@ struct Rccl {
   nccl_result_t (*CommDestroy)(nccl_comm_t) = nullptr;
   nccl_result_t (*AllReduce)(const void*, void*, size_t, int, int, nccl_comm_t, hipStream_t) = nullptr;
   const char* (*GetErrorString)(nccl_result_t) = nullptr;
+  nccl_result_t (*CommCount)(const nccl_comm_t, int*) = nullptr;       // optional: what RCCL itself says the communicator is
+  nccl_result_t (*CommUserRank)(const nccl_comm_t, int*) = nullptr;
   char why[256] = {0};
-  bool tried = false;
+  bool ok = false;
 };
 Rccl g_rccl;
+std::once_flag g_rccl_once;
 
+void rccl_load_once();
+// Two threads that create communicators on different handles at the same time both come through here: the dlopen and the
+// symbol table are set up exactly once, everybody else waits for that and reads the verdict.
 bool rccl_load() {
+  std::call_once(g_rccl_once, rccl_load_once);
+  return g_rccl.ok;
+}
+
+void rccl_load_once() {
   Rccl& r = g_rccl;
-  if (r.so) return true;
-  if (r.tried) return false;
-  r.tried = true;
   const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
   for (const char* nm : names)
     if ((r.so = dlopen(nm, RTLD_NOW | RTLD_GLOBAL))) break;
-  if (!r.so) { snprintf(r.why, sizeof(r.why), "librccl.so.1 not found (%s)", dlerror()); return false; }
+  if (!r.so) { snprintf(r.why, sizeof(r.why), "librccl.so.1 not found (%s)", dlerror()); return; }
   r.GetUniqueId = (decltype(r.GetUniqueId))dlsym(r.so, "ncclGetUniqueId");
   r.CommInitRank = (decltype(r.CommInitRank))dlsym(r.so, "ncclCommInitRank");
   r.CommDestroy = (decltype(r.CommDestroy))dlsym(r.so, "ncclCommDestroy");
   r.AllReduce = (decltype(r.AllReduce))dlsym(r.so, "ncclAllReduce");
   r.GetErrorString = (decltype(r.GetErrorString))dlsym(r.so, "ncclGetErrorString");
+  r.CommCount = (decltype(r.CommCount))dlsym(r.so, "ncclCommCount");
+  r.CommUserRank = (decltype(r.CommUserRank))dlsym(r.so, "ncclCommUserRank");
   if (!r.GetUniqueId || !r.CommInitRank || !r.CommDestroy || !r.AllReduce) {
     snprintf(r.why, sizeof(r.why), "librccl.so.1 lacks an expected symbol");
     dlclose(r.so); r.so = nullptr;
-    return false;
+    return;
   }
-  return true;
+  r.ok = true;
 }
 
 int nccl_fail(sfm_ctx* h, const char* what, nccl_result_t e) {
@@ -103,6 +114,11 @@ extern "C" int sfm_comm_destroy(sfm_handle h) {
 extern "C" int sfm_comm_info(sfm_handle h, int32_t* n_ranks, int32_t* rank) {
   if (!h || !n_ranks || !rank) return SFM_ERR_ARG;
   *n_ranks = h->comm ? h->comm_ranks : 0; *rank = h->comm ? h->comm_rank : 0;
+  // RCCL's own word where it offers one: the ranks the communicator actually spans, not what the caller said it would
+  if (h->comm && g_rccl.CommCount && g_rccl.CommUserRank) {
+    int c = 0, u = 0;
+    if (!g_rccl.CommCount((nccl_comm_t)h->comm, &c) && !g_rccl.CommUserRank((nccl_comm_t)h->comm, &u)) { *n_ranks = c; *rank = u; }
+  }
   return SFM_OK;
 }
 

@@ -9,7 +9,6 @@
 #define SFM_PROF_RING 128
 #define SFM_PINNED_DOUBLES 64
 #define SFM_PIN_CG1 32
-#define SFM_PIN_CG2 40
 struct sfm_prof_slot {
   hipEvent_t start[SFM_PROF_RING], stop[SFM_PROF_RING];
   int pending;             // recorded, not yet folded into total_ms
@@ -22,7 +21,8 @@ struct sfm_ctx {
   hipStream_t stream;
   char err[512];
   double* pinned;          // SFM_PINNED_DOUBLES of pinned host memory: [0, SFM_SC_COUNT) scalar read-back, then the status words
-                           // of the two camera-CG systems of a damped solve (SFM_PIN_CG1, SFM_PIN_CG2: 8 doubles each)
+                           // of the first camera-CG system of a damped solve (SFM_PIN_CG1, 8 doubles; the second system's live in
+                           // the problem's own pinned block, sfm_ba_prob::host_sc)
   hipEvent_t cg_event;     // recorded behind the status copy of the first system (sfm_ba_schur_solve waits for it, not for the stream)
   int profiling;
   sfm_prof_slot prof[SFM_PROF_COUNT];
@@ -30,7 +30,6 @@ struct sfm_ctx {
   size_t scratch_bytes;
   void* comm;              // ncclComm_t of this handle (comm_rccl.hip), or null
   int comm_owned, comm_ranks, comm_rank;
-  unsigned cgs_seq;        // k_cgs_persist: per-launch salt of the granule tags (24 bits, never 0)
   int cgs_persist_off;     // set once a persistent CG launch had to be abandoned: per-launch kernel from then on
 };
 

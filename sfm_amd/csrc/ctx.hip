@@ -24,7 +24,6 @@ extern "C" int sfm_create(int device, sfm_handle* out) {
   h->scratch = nullptr;
   h->scratch_bytes = 0;
   h->comm = nullptr; h->comm_owned = 0; h->comm_ranks = 0; h->comm_rank = 0;
-  h->cgs_seq = 0;
   h->cgs_persist_off = 0;
   memset(h->prof, 0, sizeof(h->prof));
   if ((e = hipHostMalloc((void**)&h->pinned, SFM_PINNED_DOUBLES * sizeof(double), hipHostMallocDefault)) != hipSuccess) {

@@ -195,11 +195,11 @@ extern "C" int sfm_ba_create_problem(sfm_handle h, const sfm_ba_desc* d, sfm_ba_
   p->n_cams = C; p->n_pts = P; p->cam_dim = d->cam_dim; p->apply_reg = d->apply_reg; p->precision = d->precision;
   p->camera_solver = d->camera_solver;
   // pinned host mirror of the scalars (every kernel that writes one writes it here too: sfm_ba_read_scalars only waits)
-  if (hipHostMalloc((void**)&p->host_sc, SFM_SC_COUNT * sizeof(double), hipHostMallocDefault) != hipSuccess) {
+  if (hipHostMalloc((void**)&p->host_sc, (SFM_SC_COUNT + 8) * sizeof(double), hipHostMallocDefault) != hipSuccess) {
     p->host_sc = nullptr; sfm_ba_destroy_problem(p);
     return sfm_fail(h, SFM_ERR_HIP, "sfm_ba_create_problem", "pinned host memory for the scalars");
   }
-  memset(p->host_sc, 0, SFM_SC_COUNT * sizeof(double));
+  memset(p->host_sc, 0, (SFM_SC_COUNT + 8) * sizeof(double));
   p->n_obs = N;
   p->fx0 = d->fx0; p->fy0 = d->fy0; p->cx0 = d->cx0; p->cy0 = d->cy0;
   p->width = d->width; p->height = d->height; p->reg_weight = d->reg_weight;
@@ -424,5 +424,10 @@ extern "C" int sfm_ba_bind_workspace(sfm_handle h, sfm_ba_problem p, void* works
   if (workspace_bytes < need) return sfm_fail(h, SFM_ERR_WORKSPACE, "sfm_ba_bind_workspace", "workspace too small");
   p->workspace = workspace;
   p->workspace_bytes = workspace_bytes;
+  // A caller-owned workspace may have served another problem (or another handle) before.  The persistent camera CG validates
+  // what it reads from its mailbox by tags alone, so the mailbox must not hold a previous owner's granules: cleared here, with
+  // the CG status words (the salts are process-wide and never repeat either - cgs_persist_launch).
+  SFM_HIP(h, hipMemsetAsync((double*)workspace + p->L.cg_mail, 0, (size_t)(4 * (int64_t)p->n_cams * p->cam_dim) * sizeof(double), h->stream));
+  SFM_HIP(h, hipMemsetAsync((double*)workspace + p->L.cg_scal, 0, 16 * sizeof(double), h->stream));
   return SFM_OK;
 }

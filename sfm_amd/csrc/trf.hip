@@ -122,6 +122,7 @@ extern "C" int sfm_ba_trf_begin(sfm_handle h, sfm_ba_problem p, double* x, const
   sfm_trf_state_s* s = new sfm_trf_state_s();
   s->h = h; s->p = p; s->x = x; s->x_new = nullptr; s->opt = *opt; s->reduce = reduce; s->reduce_user = reduce_user;
   s->cg_iters = 0;
+  if (reduce) p->sharded = 1;          // one rank of several: no rank-local route switches in the replicated camera solve
   sfm_ba_get_layout(p, &s->lay);
   const size_t bytes = ((size_t)p->n_cams * p->cam_dim + 3 * (size_t)p->n_pts) * sizeof(double);
   if (hipMalloc((void**)&s->x_new, bytes) != hipSuccess) { delete s; return sfm_fail(h, SFM_ERR_HIP, "sfm_ba_trf_begin", "hipMalloc"); }

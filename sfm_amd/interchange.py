@@ -35,11 +35,14 @@ def save_pair_data(data_dir, pair_name, pts1, pts2, F, inlier_mask, matches):
     np.save(corr / f'{pair_name}_pts1.npy', pts1[inlier_mask])
     np.save(corr / f'{pair_name}_pts2.npy', pts2[inlier_mask])
     np.savez(fund / f'{pair_name}_F.npz', F=F, mask=inlier_mask, pts1=pts1, pts2=pts2)
-    np.savez(mdir / f'{pair_name}_matches.npz',
-             queryIdx=np.array([m.queryIdx for m in matches]),
-             trainIdx=np.array([m.trainIdx for m in matches]),
-             distance=np.array([m.distance for m in matches]),
-             inlier_mask=inlier_mask)
+    if hasattr(matches, "queryIdx") and len(matches) > 0:
+        # a DMatchList (sfm_amd.matcher): the arrays are there already; dtypes as np.array() of Python ints / floats gives them
+        qi, ti, di = (np.asarray(matches.queryIdx, dtype=np.int64), np.asarray(matches.trainIdx, dtype=np.int64),
+                      np.asarray(matches.distance, dtype=np.float64))
+    else:
+        qi, ti, di = (np.array([m.queryIdx for m in matches]), np.array([m.trainIdx for m in matches]),
+                      np.array([m.distance for m in matches]))
+    np.savez(mdir / f'{pair_name}_matches.npz', queryIdx=qi, trainIdx=ti, distance=di, inlier_mask=inlier_mask)
 
 
 def load_pair_data(data_dir, pair_name):

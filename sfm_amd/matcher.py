@@ -5,6 +5,7 @@ No CPU fallback."""
 from __future__ import annotations
 
 import ctypes as C
+from collections.abc import Sequence
 
 import numpy as np
 
@@ -24,6 +25,68 @@ class DMatch:
 
     def __repr__(self):
         return f"DMatch(queryIdx={self.queryIdx}, trainIdx={self.trainIdx}, distance={self.distance})"
+
+    def __eq__(self, other):
+        return (isinstance(other, DMatch) and (self.queryIdx, self.trainIdx, self.distance, self.imgIdx) ==
+                (other.queryIdx, other.trainIdx, other.distance, other.imgIdx))
+
+    __hash__ = None
+
+
+def _dmatch(q, t, d):
+    """A DMatch from values that already are Python int / float (ndarray.tolist()): no conversions, no __init__ call."""
+    m = DMatch.__new__(DMatch)
+    m.queryIdx, m.trainIdx, m.distance, m.imgIdx = q, t, d, 0
+    return m
+
+
+class DMatchList(Sequence):
+    """What `match_features` returns: the matches of one image pair as a read-only sequence over the three result arrays.
+
+    Everything the reference does with the list works - `len(matches)` (find_matches.py:274,305), iteration in query order with
+    `.queryIdx / .trainIdx / .distance` on every element (:230-232, 278-279, 323-327), indexing, slicing, truthiness,
+    `list(matches)` - but no object exists until one is asked for: building 30,000 DMatch objects up front cost two orders of
+    magnitude more than the kernels that found the matches (50k x 50k: 0.4 ms on the GPU).  Array consumers read
+    `.queryIdx`, `.trainIdx`, `.distance` (int32 / int32 / float32 NumPy arrays, query order) and skip the objects altogether:
+    `pts1 = kp_xy[matches.queryIdx]` is the vector form of find_matches.py:278."""
+
+    __slots__ = ("queryIdx", "trainIdx", "distance")
+
+    def __init__(self, queryIdx, trainIdx, distance):
+        self.queryIdx = np.asarray(queryIdx, dtype=np.int32)
+        self.trainIdx = np.asarray(trainIdx, dtype=np.int32)
+        self.distance = np.asarray(distance, dtype=np.float32)
+        if not (self.queryIdx.ndim == 1 and self.queryIdx.shape == self.trainIdx.shape == self.distance.shape):
+            raise ValueError("queryIdx, trainIdx and distance must be 1-D arrays of one length")
+
+    def __len__(self):
+        return int(self.queryIdx.shape[0])
+
+    def __getitem__(self, i):
+        if isinstance(i, slice):
+            return DMatchList(self.queryIdx[i], self.trainIdx[i], self.distance[i])
+        i = int(i)
+        n = len(self)
+        if i < -n or i >= n:
+            raise IndexError("DMatchList index out of range")
+        return _dmatch(int(self.queryIdx[i]), int(self.trainIdx[i]), float(self.distance[i]))
+
+    def __iter__(self):
+        # one tolist() per array, then objects one at a time: nothing of the pair is held beyond the element in hand
+        return map(_dmatch, self.queryIdx.tolist(), self.trainIdx.tolist(), self.distance.tolist())
+
+    def __eq__(self, other):
+        if isinstance(other, DMatchList):
+            return (np.array_equal(self.queryIdx, other.queryIdx) and np.array_equal(self.trainIdx, other.trainIdx) and
+                    np.array_equal(self.distance, other.distance))
+        if isinstance(other, (list, tuple)):
+            return len(other) == len(self) and all(a == b for a, b in zip(self, other))
+        return NotImplemented
+
+    __hash__ = None
+
+    def __repr__(self):
+        return f"DMatchList({len(self)} matches)"
 
 
 def _to_device(a, device):
@@ -284,8 +347,9 @@ class ImageMatcher(VerificationMixin):
         self.device = device
 
     def match_features(self, desc1, desc2):
+        """Returns a DMatchList: the reference's list of cv2.DMatch as a lazy sequence (see DMatchList)."""
         q, t, d = match_arrays(desc1, desc2, self.ratio, self.metric, self.device)
-        return [DMatch(a, b, c) for a, b, c in zip(q.tolist(), t.tolist(), d.tolist())]
+        return DMatchList(q, t, d)
 
     def match_features_batched(self, descs, pairs):
         """match_features(descs[i], descs[j]) for every (i, j) of `pairs` in one launch: the list the reference's
@@ -298,6 +362,5 @@ class ImageMatcher(VerificationMixin):
                 logging.error(f"Error processing pair ({i}, {j}): {res}")
                 out.append(None)
                 continue
-            q, t, d = res
-            out.append([DMatch(a, b, c) for a, b, c in zip(q.tolist(), t.tolist(), d.tolist())])
+            out.append(DMatchList(*res))
         return out

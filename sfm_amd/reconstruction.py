@@ -69,13 +69,21 @@ def pack_state(poses, points3D, point_tracks, K, cam_dim=10, order="reference"):
     lens, cam_idx, uv = _flatten_tracks(point_tracks, id_to_idx)
     pt_idx = np.repeat(np.arange(len(point_tracks), dtype=np.int64), lens)
     if order == "reference":
-        perm = np.argsort(cam_idx, kind="stable")
-        eff = np.empty_like(uv)
-        eff[perm] = uv
-        uv = eff
+        uv = reference_pairing(uv, cam_idx)
     elif order != "aligned":
         raise ValueError(f"unknown order {order!r}")
     return cams, pts, cam_idx, pt_idx, uv, ids
+
+
+def reference_pairing(uv, cam_idx):
+    """The pixel each observation is compared with under the reference's residual pairing (sfm_reconstruction.py:480-486):
+    projections are stacked camera by camera, `points2D` stays point-major, so the q-th observation in stable camera-sorted
+    order meets the q-th point-major pixel."""
+    uv = np.asarray(uv)
+    perm = np.argsort(np.asarray(cam_idx), kind="stable")
+    eff = np.empty_like(uv)
+    eff[perm] = uv
+    return eff
 
 
 class BundleAdjustMixin:

@@ -1,6 +1,7 @@
 """CPU tests: oracle vs the reference-generated goldens, the host-side TRF state machine and index
 structures, the sharded (multi-rank) algebra over gloo, and the C-ABI surface."""
 import ctypes
+import json
 import os
 import re
 import subprocess
@@ -432,3 +433,82 @@ def test_native_trf_loop_equals_python_loop_under_sanitizers(tmp_path, ftol, xto
     assert (nfev, njev, status, n_trials) == (ref.nfev, ref.njev, ref.status, len(ref.trace))
     assert cost == pytest.approx(ref.cost, rel=1e-9)
     assert np.allclose(x, be.x, rtol=1e-8, atol=1e-10)
+
+
+def test_dmatchlist_serves_every_use_the_reference_makes_of_the_match_list(tmp_path):
+    """/root/reference/utils/find_matches.py: len() (:274, :305), iteration with attribute reads (:230-232, :278-279,
+    :323-327); plus indexing, slicing, equality with a plain list, and the byte-identical match file."""
+    from sfm_amd.matcher import DMatch, DMatchList
+    from sfm_amd import interchange
+    q = np.array([0, 3, 4, 9], dtype=np.int32)
+    t = np.array([7, 1, 1, 2], dtype=np.int32)
+    d = np.sqrt(np.array([5, 100, 7, 12], dtype=np.float32))
+    ms = DMatchList(q, t, d)
+    plain = [DMatch(a, b, c) for a, b, c in zip(q, t, d)]
+    assert len(ms) == 4 and bool(ms) and not DMatchList(q[:0], t[:0], d[:0]) and DMatchList(q[:0], t[:0], d[:0]) == []
+    assert [m.queryIdx for m in ms] == [0, 3, 4, 9] and [m.trainIdx for m in ms] == [7, 1, 1, 2]
+    assert all(type(m.queryIdx) is int and type(m.distance) is float and m.imgIdx == 0 for m in ms)
+    assert [m.distance for m in ms] == [float(v) for v in d]
+    assert ms[1] == plain[1] and ms[-1] == plain[-1] and ms == plain and list(ms) == plain
+    assert isinstance(ms[1:3], DMatchList) and ms[1:3] == plain[1:3]
+    with pytest.raises(IndexError):
+        ms[4]
+    kp = np.arange(20, dtype=np.float32).reshape(10, 2)
+    assert np.array_equal(np.float32([kp[m.queryIdx] for m in ms]).reshape(-1, 2), kp[ms.queryIdx])    # :278, vector form
+    pts = np.zeros((4, 2), np.float32)
+    mask = np.array([True, False, True, True])
+    interchange.save_pair_data(tmp_path / "a", "p", pts, pts, np.eye(3), mask, ms)
+    interchange.save_pair_data(tmp_path / "b", "p", pts, pts, np.eye(3), mask, plain)
+    za, zb = np.load(tmp_path / "a" / "matches" / "p_matches.npz"), np.load(tmp_path / "b" / "matches" / "p_matches.npz")
+    assert all(za[k].dtype == zb[k].dtype and np.array_equal(za[k], zb[k]) for k in zb.files)
+
+
+# ------------------------------------------------------------------ bench.py starts its own ranks (`python bench.py --gpus N`)
+def _bench_launch(extra, child=None, timeout=60):
+    import subprocess
+    import time
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py")] + extra
+    if child is not None:
+        cmd += ["--child-cmd", json.dumps([sys.executable, "-c", child])]
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    t0 = time.monotonic()
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=timeout)
+    return r, time.monotonic() - t0
+
+
+def test_bench_dry_launch_prints_the_plan():
+    r, _ = _bench_launch(["--gpus", "8", "--steps", "7", "--warmup", "2", "--dry-launch"])
+    assert r.returncode == 0
+    plan = json.loads(r.stdout.strip().splitlines()[-1])
+    assert plan["world_size"] == 8 and plan["master_addr"] == "127.0.0.1" and 0 < plan["master_port"] < 65536
+    assert [x["RANK"] for x in plan["ranks"]] == list(range(8)) and all(x["WORLD_SIZE"] == 8 for x in plan["ranks"])
+    assert plan["command"][1].endswith("bench.py") and plan["command"][2:] == ["--gpus", "8", "--steps", "7", "--warmup", "2"]
+
+
+def test_bench_launcher_relays_rank_zero_and_sets_the_rank_environment():
+    child = ("import os, json, sys; r = int(os.environ['RANK']); "
+             "assert os.environ['WORLD_SIZE'] == '3' and os.environ['LOCAL_RANK'] == str(r) and os.environ['MASTER_ADDR'] == '127.0.0.1'; "
+             "print('noise from rank', r); "
+             "print(json.dumps({'metric': 'stub', 'rank': r, 'port': int(os.environ['MASTER_PORT'])})) if r == 0 else None")
+    r, _ = _bench_launch(["--gpus", "3"], child)
+    assert r.returncode == 0, r.stderr
+    out = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(out) == 1 and json.loads(out[0])["metric"] == "stub" and json.loads(out[0])["rank"] == 0
+    assert "noise from rank 1" in r.stderr and "noise from rank 2" in r.stderr       # other ranks' stdout never reaches ours
+
+
+def test_bench_launcher_stops_everything_when_one_rank_fails():
+    child = "import os, sys, time; r = int(os.environ['RANK']); sys.exit(7) if r == 1 else time.sleep(120)"
+    r, took = _bench_launch(["--gpus", "2"], child)
+    assert r.returncode == 7 and took < 30 and r.stdout.strip() == "" and "rank 1 exited with 7" in r.stderr
+
+
+def test_bench_launcher_kills_a_silent_group_at_its_bound():
+    child = "import time; time.sleep(120)"
+    r, took = _bench_launch(["--gpus", "2", "--launch-timeout", "1.5"], child)
+    assert r.returncode == 124 and took < 30 and r.stdout.strip() == ""
+
+
+def test_bench_launcher_fails_when_rank_zero_prints_no_line():
+    r, _ = _bench_launch(["--gpus", "2"], "print('nothing useful')")
+    assert r.returncode == 1 and "no JSON line" in r.stderr
