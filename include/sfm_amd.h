@@ -141,6 +141,12 @@ enum { SFM_CAMERA_SOLVER_AUTO = 0,       /* CG on the block-scaled system (n = n
                                             does not converge (160 / 400 iterations) or meets non-positive curvature */
 enum { SFM_BA_FP64 = 0,    /* every intermediate in float64 (default; the reference's arithmetic) */
        SFM_BA_MIXED = 1 }; /* Jacobian rows (and scaled residuals) stored in float32; every sum, W L^-T, S and the solve in float64 */
+enum { SFM_UV_AS_GIVEN = 0,           /* observation k is compared with uv[k] */
+       SFM_UV_REFERENCE_PAIRING = 1 }; /* the reference's own residual (sfm_reconstruction.py:480-486): projections are stacked camera
+                                          by camera, `points2D` stays point-major, so the q-th observation in stable camera-sorted
+                                          order meets uv[q].  Applied on the device from the camera-sorted list the problem builds
+                                          anyway.  The pairing is a permutation of ALL observations: a sharded host applies it
+                                          before it shards (sfm_amd.reconstruction.reference_pairing) and passes SFM_UV_AS_GIVEN */
 typedef struct {
   int32_t n_cams, n_pts, cam_dim, apply_reg;   /* apply_reg: add the 4 regulariser rows per camera (:489-499); rank 0 only */
   int64_t n_obs;
@@ -151,6 +157,8 @@ typedef struct {
   double width, height, reg_weight;
   int32_t precision;         /* SFM_BA_FP64 | SFM_BA_MIXED */
   int32_t camera_solver;     /* how sfm_ba_schur_solve solves the formed n x n camera system: SFM_CAMERA_SOLVER_* */
+  int32_t uv_pairing;        /* SFM_UV_AS_GIVEN | SFM_UV_REFERENCE_PAIRING */
+  int32_t reserved;          /* 0 */
 } sfm_ba_desc;
 
 typedef struct sfm_ba_prob* sfm_ba_problem;    /* opaque; owns its index structure (device memory) */

@@ -21,6 +21,7 @@ i32, i64, f64, vp = C.c_int32, C.c_int64, C.c_double, C.c_void_p
 PREC_FP64, PREC_MIXED = 0, 1
 SOLVER_DENSE, SOLVER_PCG = 0, 1
 CAMERA_AUTO, CAMERA_CHOLESKY, CAMERA_CG = 0, 1, 2
+UV_AS_GIVEN, UV_REFERENCE_PAIRING = 0, 1
 
 
 class BADesc(C.Structure):
@@ -30,7 +31,7 @@ class BADesc(C.Structure):
                 ("cam_idx", vp), ("pt_idx", vp), ("uv", vp),
                 ("fx0", f64), ("fy0", f64), ("cx0", f64), ("cy0", f64),
                 ("width", f64), ("height", f64), ("reg_weight", f64),
-                ("precision", i32), ("camera_solver", i32)]
+                ("precision", i32), ("camera_solver", i32), ("uv_pairing", i32), ("reserved", i32)]
 
 
 class BAStructureView(C.Structure):

@@ -34,6 +34,8 @@ class GpuBA:
     the solve stay float64).  solver="dense" forms the reduced camera system and factors it (default);
     solver="pcg" solves it by preconditioned conjugate gradients on the implicit Schur complement
     (sfm_ba_solve_pcg): no n x n matrix, one n-vector exchanged per iteration between ranks.
+    uv_pairing="reference": the library pairs observations and pixels as the reference's objective does (sfm_reconstruction.py:
+    480-486: the q-th observation in camera-sorted order meets uv[q]) on the device; "as_given": observation k meets uv[k].
     camera_solver (solver="dense" only): how the formed system is solved - "auto" (default): conjugate gradients on
     the block-scaled system (n <= 2048: one persistent launch per system; up to 4096: one launch per iteration; beyond:
     tile-streaming over the symmetric half of the matrix), with the bordered Cholesky as fallback; "cholesky" / "cg"
@@ -42,7 +44,7 @@ class GpuBA:
 
     def __init__(self, cams, pts, cam_idx, pt_idx, uv, K0, width=1024.0, height=768.0,
                  reg_weight=0.1, device=0, comm=None, precision="fp64", solver="dense", pcg_rtol=1e-13,
-                 pcg_max_iter=None, camera_solver="auto"):
+                 pcg_max_iter=None, camera_solver="auto", uv_pairing="as_given"):
         import torch
         self.torch = torch
         self.comm = comm or LocalComm()
@@ -83,6 +85,11 @@ class GpuBA:
         d.width, d.height, d.reg_weight = float(width), float(height), float(reg_weight)
         d.precision = _lib.PREC_MIXED if precision == "mixed" else _lib.PREC_FP64
         d.camera_solver = {"auto": _lib.CAMERA_AUTO, "cholesky": _lib.CAMERA_CHOLESKY, "cg": _lib.CAMERA_CG}[camera_solver]
+        if uv_pairing not in ("as_given", "reference"):
+            raise ValueError(f"unknown uv_pairing {uv_pairing!r}")
+        if uv_pairing == "reference" and self.comm.world_size > 1:
+            raise ValueError("the reference pairing permutes ALL observations: apply it before sharding (reference_pairing)")
+        d.uv_pairing = _lib.UV_REFERENCE_PAIRING if uv_pairing == "reference" else _lib.UV_AS_GIVEN
         self.desc = d
         self._pp = _lib.vp()
         rc = self.h.lib.sfm_ba_create_problem(self.h._h, C.byref(d), C.byref(self._pp))

@@ -84,7 +84,7 @@ Lay ba_layout(int64_t C, int64_t P, int64_t N, int64_t D, int64_t n_items, int64
   // implicit-Schur PCG (sfm_ba_solve_pcg): residual, preconditioned residual, direction, S p; block-Jacobi blocks
   L.cg_r = take(n); L.cg_z = take(n); L.cg_p = take(n); L.cg_Ap = take(n);
   L.cg_M = take(C * D * D); L.cg_Minv = take(C * D * D);
-  L.cg_scal = take(16);
+  L.cg_scal = take(64);                  // [0, 16) status words of the camera CG; [16, 32) / [32, 48): XCD tickets of its two launches
   L.cg_mail = take(4 * n);               // k_cgs_persist: two slots of n doubles as pairs of 8-byte {tag, half} granules
   L.cg_warm = take(4 * n);               // warm start of the camera CG: p_c and q_c of the previous damped solve, start vector, scratch
   L.total = o;
@@ -912,7 +912,7 @@ __global__ __launch_bounds__(256) void k_schur_assemble(int C, const int* __rest
   // the status words of the camera CG that follows start from zero (k_diag_einv only ever RAISES its failure word): cleared
   // here, by the kernel that always runs before it, instead of by a memset between two kernels of the chain (a fill kernel of
   // its own, ~5 us with its boundaries)
-  if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x < 16) cg_scal[threadIdx.x] = 0.0;
+  if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x < 64) cg_scal[threadIdx.x] = 0.0;
   // ... and the right-hand side r_c = g_c - sum over the camera's chunk partials of sum_k G_k e_j (they came out of the
   // diagonal-block items, or of the camera-wise pass): the first workgroup of a block row adds them up, four slots of chunks
   // side by side as k_cam_reduce_final does - that kernel was a launch of its own here (4.8 us plus a boundary)
@@ -1427,6 +1427,7 @@ extern "C" int sfm_ba_linearize(sfm_handle h, sfm_ba_problem p, const double* x)
   const int64_t N = p->n_obs;
   const double* pts = x + (size_t)n;
   p->warm_pc_ok = p->warm_qc_ok = 0;                  // a new linearisation: the previous damped solves are another system's
+  p->cgp_fail_rel *= 0.8;                             // ... and what was hopeless for the camera CG there may not be here: let it try lower again
   DISPATCH_DT(D, p->precision, {
     hipLaunchKernelGGL(k_campre<DD>, dim3(cdiv(C, 64)), dim3(64), 0, h->stream, x, C, p->fx0, p->fy0, p->cx0,
                        p->cy0, WS(L, campre));
@@ -1590,7 +1591,10 @@ __global__ void k_finish_solve_pcg(int n, const double* __restrict__ pc, const d
 constexpr int CGS_MAX_N = 4096;          // the direction vector lives in LDS (32 KB); larger systems use the factorisation
 constexpr int CGS_MAX_ITER = 160;
 constexpr int CGS_BIG_MAX_ITER = 400;   // the tile-streaming route for n > CGS_MAX_N (cgs_solve_big)
-constexpr double CGS_RTOL = 1e-13;       // ||r|| <= CGS_RTOL ||r_0|| on the scaled system
+// ||r|| <= CGS_RTOL ||r_0|| on the scaled system.  SFM_CGS_RTOL overrides it - a DIAGNOSTIC knob (tools/exp_cg_fixed_cost.py
+// sets 1.0: zero iterations, what remains is the fixed cost of a system), never set by the product
+static double cgs_rtol() { static const double v = getenv("SFM_CGS_RTOL") ? atof(getenv("SFM_CGS_RTOL")) : 1e-13; return v; }
+#define CGS_RTOL cgs_rtol()
 enum { CGS_RR0 = 0, CGS_RR = 1, CGS_ITER = 2, CGS_FAIL = 3, CGS_DONE = 4,
        CGS_RR_SLOT = 5 };   // [5], [6]: ||r||^2 handed from launch to launch; launch `it` reads slot (it + 1) & 1, writes slot it & 1
 
@@ -1838,16 +1842,39 @@ __global__ __launch_bounds__(256, 1) void k_cgs_persist(int n, double rtol2, int
                                                         const double* __restrict__ x0 /* may be null: start from 0 */,
                                                         double* __restrict__ x_out, pr_u64* mail /* [2][n][2] granules */,
                                                         pr_u64* abort_w, double* __restrict__ scal, PrFuse f, int sabotage,
-                                                        double* __restrict__ host_status /* pinned host memory, device-mapped: 8 words */) {
-  // test hook (SFM_CGS_SABOTAGE=1): workgroup 1 never publishes, as if it had not become resident - the others must run into
-  // their spin bound, post the abort word and leave; the host then takes the launch-per-iteration route
-  if (sabotage > 0 && blockIdx.x == 1) return;
+                                                        double* __restrict__ host_status /* pinned host memory, device-mapped: 8 words */,
+                                                        unsigned* __restrict__ tickets /* null: every workgroup of the grid works */) {
   __shared__ double s_part[PR_ROWS][4];
   __shared__ double s_red[4];
   __shared__ int s_ok[4];
+  __shared__ int s_blk;
   __shared__ double s_x[PR_MAX_N];                  // workgroup 0, epilogue: x~ for the block-wise back-transformation
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-  const int row0 = (int)blockIdx.x * PR_ROWS;
+  // ONE-XCD MODE (tickets != null; n <= PR_XCD_MAX_N): the grid is 8 x the workgroups the system needs, dealt round-robin over
+  // the XCDs by the dispatcher; only the workgroups that find themselves on XCD 0 work, each on the block of rows its ticket
+  // names, the rest leave at once.  The all-gather then never leaves that XCD's L2: entries are published with PLAIN stores
+  // (the line stays in L2) and polled with loads that bypass L1 only - a hop is an L2 access, where the device-wide form pays
+  // the fabric twice per iteration (store to the memory side, reload from it).  Same arithmetic in the same order: bitwise the
+  // device-wide result.  Placement is a speed matter only: should fewer than `need` workgroups ever land on XCD 0, the ones
+  // that did see it (all 8 x need tickets drawn, XCD 0 short) and abandon the launch; the host then uses the device-wide form.
+  const bool one_xcd = tickets != nullptr;
+  const int need = (n + PR_ROWS - 1) / PR_ROWS;
+  int blk = (int)blockIdx.x;
+  if (one_xcd) {
+    if (tid == 0) {
+      const unsigned xcc = (unsigned)__builtin_amdgcn_s_getreg((3 << 11) | 20) & 7u;        // HW_REG_XCC_ID[3:0]
+      const unsigned t = __hip_atomic_fetch_add(tickets + xcc, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_fetch_add(tickets + 8, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      s_blk = (xcc == 0u && t < (unsigned)need) ? (int)t : -1;
+    }
+    __syncthreads();
+    blk = s_blk;
+    if (blk < 0) return;
+  }
+  // test hook (SFM_CGS_SABOTAGE=1): workgroup 1 never publishes, as if it had not become resident - the others must run into
+  // their spin bound, post the abort word and leave; the host then takes the launch-per-iteration route
+  if (sabotage > 0 && blk == 1) return;
+  const int row0 = blk * PR_ROWS;
   // this thread's slice of the workgroup's rows: registers for the whole solve
   double2 sv[PR_ROWS][NC];
 #pragma unroll
@@ -1916,7 +1943,8 @@ __global__ __launch_bounds__(256, 1) void k_cgs_persist(int n, double rtol2, int
       // from one instruction); each 8-byte half carries its own tag, so the store need not be atomic as a whole
       typedef unsigned pr_st4 __attribute__((ext_vector_type(4)));
       const pr_st4 pk = {(unsigned)(bits & 0xFFFFFFFFull), tag, (unsigned)(bits >> 32), tag};
-      asm volatile("global_store_dwordx4 %0, %1, off sc1" :: "v"(slot + 2 * (size_t)(row0 + tid)), "v"(pk) : "memory");
+      if (one_xcd) asm volatile("global_store_dwordx4 %0, %1, off" :: "v"(slot + 2 * (size_t)(row0 + tid)), "v"(pk) : "memory");
+      else asm volatile("global_store_dwordx4 %0, %1, off sc1" :: "v"(slot + 2 * (size_t)(row0 + tid)), "v"(pk) : "memory");
     }
     // gather this thread's columns: 4 granules per chunk (two doubles), re-read until every tag matches
     bool ok = false;
@@ -1953,7 +1981,11 @@ __global__ __launch_bounds__(256, 1) void k_cgs_persist(int n, double rtol2, int
         yv[2 * c + 1] = in ? __longlong_as_double((long long)((g[4 * c + 2] & 0xFFFFFFFFull) | (g[4 * c + 3] << 32))) : 0.0;
       }
       if (__all(all)) { ok = true; break; }
-      if ((spins & 31u) == 31u && __hip_atomic_load(abort_w, PR_RLX_AGENT) == (pr_u64)salt) break;     // somebody gave up
+      if ((spins & 31u) == 31u) {
+        if (__hip_atomic_load(abort_w, PR_RLX_AGENT) == (pr_u64)salt) break;     // somebody gave up
+        if (one_xcd && __hip_atomic_load(tickets + 8, PR_RLX_AGENT) == 8u * (unsigned)need &&
+            __hip_atomic_load(tickets, PR_RLX_AGENT) < (unsigned)need) break;     // every ticket is drawn and XCD 0 holds too few
+      }
       __builtin_amdgcn_s_sleep(2);                    // (polling without the sleep measured the same: 135.1 / 100.1 us per system)
     }
     if (lane == 0) s_ok[w] = ok ? 1 : 0;
@@ -1966,7 +1998,7 @@ __global__ __launch_bounds__(256, 1) void k_cgs_persist(int n, double rtol2, int
   // done: 1 = the recurrence ended (converged, or broken: fail 2), 0 = out of iterations, -1 = the launch was abandoned.
   // CGS_FAIL may already hold k_diag_einv's 1 (a diagonal block is not positive definite): it is only ever raised here.
   auto finish = [&](double rr, int it, double done, double fail) {
-    if (blockIdx.x != 0) return;
+    if (blk != 0) return;
 #pragma unroll
     for (int c = 0; c < NC; ++c) {
       const int col = 2 * tid + 512 * c;
@@ -2095,55 +2127,89 @@ static unsigned cgs_next_salt() {
   do { s = (seq.fetch_add(1u, std::memory_order_relaxed) + 1u) & 0xFFFFFFu; } while (s == 0u);
   return s;
 }
-static int cgs_persist_launch(sfm_ctx* h, int n, int D, const double* St, const double* rhs, const double* x0_t, double* x_t, double* mail,
-                              double* scal, double rtol, const PrFuse& fuse, double* pin) {
-  const unsigned grid = (unsigned)cdiv(n, PR_ROWS);
+// n up to which the whole grid fits ONE XCD (32 CUs x 3 workgroups of 256 threads at <= 168 registers: NC <= 2): there the
+// all-gather can run through that XCD's L2 (k_cgs_persist, one-XCD mode).  OPT-IN (SFM_CGS_XCD=1): measured at n = 500 (cfg3,
+// tools/exp_cg_fixed_cost.py 50 20000) it saves 6 % per iteration (2.44 against 2.60 us) and costs 10 us more per launch (the
+// 8 x grid, the ticket draw): 735 against 772 LM-iterations/s at cfg3 - an iteration is bound by its wave sums, barriers and
+// the poll loop, not by where the granules travel (tools/experiments/README.md).
+constexpr int PR_XCD_MAX_N = 768;
+static bool cgs_one_xcd(sfm_ctx* h, int n) {
+  const char* e = getenv("SFM_CGS_XCD");
+  return n <= PR_XCD_MAX_N && !h->cgs_xcd_off && e && e[0] == '1';
+}
+struct PrLaunch {      // everything a (re)launch of one system needs
+  int n, D; const double* St; const double* rhs; const double* x0_t; double* x_t; double* mail; double* scal; double rtol; PrFuse fuse;
+  double* pin;         // pinned host words the kernel writes its verdict to
+  int which;           // 0: step system, 1: q system (each has its own ticket words in scal)
+};
+static int cgs_persist_launch(sfm_ctx* h, const PrLaunch& a, bool one_xcd) {
+  const int n = a.n, D = a.D;
+  const unsigned need = (unsigned)cdiv(n, PR_ROWS);
+  const unsigned grid = one_xcd ? 8u * need : need;
   const int nc = (int)cdiv(n, 512);
-  pr_u64* abort_w = (pr_u64*)(scal + 12);
+  pr_u64* abort_w = (pr_u64*)(a.scal + 12);
+  unsigned* tickets = one_xcd ? (unsigned*)(a.scal + 16 + 16 * a.which) : nullptr;
   const unsigned salt = cgs_next_salt();
-  const double rtol2 = rtol * rtol;
-  const int sabotage = (getenv("SFM_CGS_SABOTAGE") && getenv("SFM_CGS_SABOTAGE")[0] == '1' && grid > 1) ? 1 : 0;
-  pin[CGS_DONE] = -1.0;                            // what a launch that never wrote its verdict reads as: abandoned
-#define PR_LAUNCH(NC, DD_) hipLaunchKernelGGL((k_cgs_persist<NC, DD_>), dim3(grid), dim3(256), 0, h->stream, n, rtol2, CGS_MAX_ITER, salt, St, rhs, x0_t, x_t, (pr_u64*)mail, abort_w, scal, fuse, sabotage, pin)
+  const double rtol2 = a.rtol * a.rtol;
+  const int sabotage = (getenv("SFM_CGS_SABOTAGE") && getenv("SFM_CGS_SABOTAGE")[0] == '1' && need > 1) ? 1 : 0;
+  a.pin[CGS_DONE] = -1.0;                          // what a launch that never wrote its verdict reads as: abandoned
+  a.pin[7] = one_xcd ? 1.0 : 0.0;                  // (host-side note beside the verdict: which mode this launch ran in)
+#define PR_LAUNCH(NC, DD_) hipLaunchKernelGGL((k_cgs_persist<NC, DD_>), dim3(grid), dim3(256), 0, h->stream, n, rtol2, CGS_MAX_ITER, salt, a.St, a.rhs, a.x0_t, a.x_t, (pr_u64*)a.mail, abort_w, a.scal, a.fuse, sabotage, a.pin, tickets)
   if (D == 10) { if (nc <= 1) PR_LAUNCH(1, 10); else if (nc == 2) PR_LAUNCH(2, 10); else if (nc == 3) PR_LAUNCH(3, 10); else PR_LAUNCH(4, 10); }
   else { if (nc <= 1) PR_LAUNCH(1, 6); else if (nc == 2) PR_LAUNCH(2, 6); else if (nc == 3) PR_LAUNCH(3, 6); else PR_LAUNCH(4, 6); }
 #undef PR_LAUNCH
   SFM_LAUNCH_CHECK(h, "cgs_persist_launch");
   return SFM_OK;
 }
-// `sharded`: the problem is one rank's shard.  Every rank must then take the SAME route through the camera solve - the routes
-// sum in different orders, so a rank that switched on its own would hold a replicated camera step that differs from its
-// peers' in the last bits, and with it, sooner or later, a different trial history and a different sequence of collectives.
-// An abandoned launch is therefore neither replaced by the launch-per-iteration route nor remembered on the handle there:
-// the caller launches the persistent kernel again (cgs_persist_retry) and, if that fails too, the solve fails loudly.
-static void cgs_persist_status(sfm_ctx* h, const double* st, int sharded, int* iters_out, int* status, int* ran) {
+static int cgs_persist_launch(sfm_ctx* h, const PrLaunch& a) { return cgs_persist_launch(h, a, cgs_one_xcd(h, a.n)); }
+static void cgs_persist_read(const double* st, int* iters_out, int* status, int* ran) {
   *ran = 0; *status = 1;
-  if (st[CGS_DONE] == -1.0) {                       // the launch was abandoned (a spin ran out)
-    if (!sharded) {
-      h->cgs_persist_off = 1;
-      fprintf(stderr, "sfm_amd: the persistent CG launch was abandoned (grid not co-resident?); using one launch per iteration from now on\n");
-    }
-    return;
-  }
+  if (st[CGS_DONE] == -1.0) return;                 // the launch was abandoned (a spin ran out, or XCD 0 came up short)
   *ran = 1;
   *iters_out += (int)st[CGS_ITER];
   if (st[CGS_FAIL] == 0.0 && st[CGS_DONE] != 0.0) *status = 0;
 }
+// The verdict of a launch has arrived (an event or a stream synchronisation behind it).  An abandoned launch is dealt with here:
+//   * it ran in one-XCD mode: that mode is switched off for the handle and the SAME system is launched again device-wide - the
+//     two modes are bitwise the same computation, so this is invisible in the results (and to the other ranks of a sharded solve);
+//   * `sharded` (the problem is one rank's shard): every rank must take the SAME route through the camera solve - the
+//     launch-per-iteration kernel sums in another order, and a rank that switched on its own would hold a replicated camera step
+//     that differs from its peers' in the last bits and, sooner or later, a different trial history and a different sequence of
+//     collectives.  So: the same kernel again, up to CGS_SHARDED_RETRIES times, then the solve fails loudly;
+//   * otherwise: *ran = 0, the handle stops using the persistent kernel and the caller takes the launch-per-iteration route.
+// *relaunched tells the caller that work enqueued behind the first launch on the assumption that it converged must be redone.
 constexpr int CGS_SHARDED_RETRIES = 3;
-// sharded problems only: launch the same system again (fresh salt), wait for it, up to CGS_SHARDED_RETRIES times
-static int cgs_persist_retry(sfm_ctx* h, int n, int D, const double* St, const double* rhs, const double* x0_t, double* x_t, double* mail,
-                             double* scal, double rtol, const PrFuse& fuse, double* pin, int* iters_out, int* status, int* ran) {
-  for (int attempt = 1; attempt <= CGS_SHARDED_RETRIES && !*ran; ++attempt) {
-    fprintf(stderr, "sfm_amd: the persistent CG launch of a sharded solve was abandoned; launching it again (%d of %d)\n", attempt, CGS_SHARDED_RETRIES);
-    SFM_HIP(h, hipMemsetAsync(scal, 0, 16 * sizeof(double), h->stream));
-    int rc = cgs_persist_launch(h, n, D, St, rhs, x0_t, x_t, mail, scal, rtol, fuse, pin); if (rc) return rc;
+static int cgs_persist_verdict(sfm_ctx* h, const PrLaunch& a, int sharded, int* iters_out, int* status, int* ran, int* relaunched) {
+  *relaunched = 0;
+  cgs_persist_read(a.pin, iters_out, status, ran);
+  if (*ran) return SFM_OK;
+  auto again = [&](bool one_xcd) -> int {
+    *relaunched = 1;
+    SFM_HIP(h, hipMemsetAsync(a.scal, 0, 64 * sizeof(double), h->stream));
+    int rc = cgs_persist_launch(h, a, one_xcd); if (rc) return rc;
     SFM_HIP(h, hipStreamSynchronize(h->stream));
-    cgs_persist_status(h, pin, 1, iters_out, status, ran);
+    cgs_persist_read(a.pin, iters_out, status, ran);
+    return SFM_OK;
+  };
+  if (a.pin[7] == 1.0) {
+    h->cgs_xcd_off = 1;
+    fprintf(stderr, "sfm_amd: the one-XCD launch of the persistent CG was abandoned (workgroups not dealt evenly over the XCDs?); using the device-wide form from now on\n");
+    int rc = again(false); if (rc) return rc;
+    if (*ran) return SFM_OK;
   }
-  if (!*ran)
-    return sfm_fail(h, SFM_ERR_HIP, "camera CG",
-                    "the persistent kernel could not run on this rank (its grid was not co-resident) and a sharded solve must take the "
-                    "same route on every rank: set SFM_CGS_PERSIST=0 on ALL ranks");
+  if (sharded) {
+    for (int attempt = 1; attempt <= CGS_SHARDED_RETRIES && !*ran; ++attempt) {
+      fprintf(stderr, "sfm_amd: the persistent CG launch of a sharded solve was abandoned; launching it again (%d of %d)\n", attempt, CGS_SHARDED_RETRIES);
+      int rc = again(false); if (rc) return rc;
+    }
+    if (!*ran)
+      return sfm_fail(h, SFM_ERR_HIP, "camera CG",
+                      "the persistent kernel could not run on this rank (its grid was not co-resident) and a sharded solve must take the "
+                      "same route on every rank: set SFM_CGS_PERSIST=0 on ALL ranks");
+    return SFM_OK;
+  }
+  h->cgs_persist_off = 1;
+  fprintf(stderr, "sfm_amd: the persistent CG launch was abandoned (grid not co-resident?); using one launch per iteration from now on\n");
   return SFM_OK;
 }
 
@@ -2425,11 +2491,43 @@ extern "C" int sfm_ba_schur_solve(sfm_handle h, sfm_ba_problem p, double alpha, 
   p->cg_state = 0;
   p->cg2_pending = 0;
   p->cg_alpha = alpha;
-  if (p->camera_solver != SFM_CAMERA_SOLVER_CHOLESKY && cgs_possible(n)) {
+  // AUTO only: a system the CG cannot finish within its budget costs the budget (160 iterations = 0.77 ms at n = 2000) AND the
+  // factorisation (0.9 ms).  SciPy's More' iteration resets alpha to 0.001 alpha_upper whenever the carried-over value falls
+  // outside its bracket (common.py:117-118) - on the spatially coherent scene that is one hopeless system every third outer
+  // iteration, seven in the first.  Whether a system is hopeless is predicted from this problem's own history; the prediction
+  // depends on replicated quantities only (alpha, max diag H, iteration counts), so every rank of a sharded solve decides alike.
+  const double hdiag = p->host_sc[SFM_SC_HDIAG];
+  const double arel = hdiag > 0.0 ? alpha / hdiag : 0.0;
+  const int cg_budget = cgs_use_big(n) ? CGS_BIG_MAX_ITER : CGS_MAX_ITER;
+  bool hopeless = false;
+  if (p->camera_solver == SFM_CAMERA_SOLVER_AUTO && arel > 0.0 && !(getenv("SFM_CGS_PREDICT") && getenv("SFM_CGS_PREDICT")[0] == '0')) {
+    if (p->cgp_fail_rel > 0.0 && arel <= 4.0 * p->cgp_fail_rel) hopeless = true;
+    else if (p->cgp_ok_its[0] > 0 && arel < p->cgp_ok_rel[0]) {
+      double slope = 0.2;                            // one record only: the flatter of the two measured exponents
+      if (p->cgp_ok_its[1] > 0) {
+        slope = -std::log((double)p->cgp_ok_its[0] / p->cgp_ok_its[1]) / std::log(p->cgp_ok_rel[0] / p->cgp_ok_rel[1]);
+        slope = slope < 0.0 ? 0.0 : (slope > 0.5 ? 0.5 : slope);
+      }
+      if (p->cgp_ok_its[0] * std::pow(p->cgp_ok_rel[0] / arel, 0.85 * slope) > 1.25 * cg_budget) hopeless = true;
+    }
+  }
+  // a converged step system joins the record: [0] the latest, [1] the one before it at an alpha at least 1.5 x away
+  auto cgp_note_ok = [&](int its) {
+    if (its <= 0) return;
+    if (p->cgp_ok_its[0] > 0) {
+      const double r = arel / p->cgp_ok_rel[0];
+      if (r >= 1.5 || r <= 1.0 / 1.5) { p->cgp_ok_rel[1] = p->cgp_ok_rel[0]; p->cgp_ok_its[1] = p->cgp_ok_its[0]; }
+    }
+    p->cgp_ok_rel[0] = arel; p->cgp_ok_its[0] = its;
+    if (arel <= p->cgp_fail_rel) p->cgp_fail_rel = 0.5 * arel;      // it does converge here after all
+  };
+  if (hopeless) p->cg_fallbacks++;
+  if (p->camera_solver != SFM_CAMERA_SOLVER_CHOLESKY && cgs_possible(n) && !hopeless) {
+    const int its_before = p->cg_iters;
     // S~ = E^-1 (S + alpha I) E^-T into the factor's buffer (S stays as it is: the fallback below needs it), r~ = E^-1 r
     sfm_prof_begin(h, SFM_PROF_CHOL);
     // (cleared by k_schur_assemble when this solve follows its own sfm_ba_schur_build, as it does in every loop of this library)
-    if (!p->cg_scal_clean) SFM_HIP(h, hipMemsetAsync(WS(L, cg_scal), 0, 16 * sizeof(double), h->stream));
+    if (!p->cg_scal_clean) SFM_HIP(h, hipMemsetAsync(WS(L, cg_scal), 0, 64 * sizeof(double), h->stream));
     p->cg_scal_clean = 0;
     DISPATCH_D(D, {
       hipLaunchKernelGGL(k_diag_einv<DD>, dim3(cdiv(C, 64)), dim3(64), 0, h->stream, C, S, n, alpha, WS(L, cg_Minv), WS(L, cg_M), WS(L, cg_scal));
@@ -2458,25 +2556,24 @@ extern "C" int sfm_ba_schur_solve(sfm_handle h, sfm_ba_problem p, double alpha, 
       // recorded behind the copy, the back-substitution is enqueued on the assumption that the solve converged (it does: 0
       // fallbacks in the bench schedules), and only then the host waits - for the event, not for the stream.
       PrFuse fuse = {WS(L, cg_Minv), nullptr, WS(L, pc), nullptr, nullptr, nullptr, nullptr, 1};      // rhs~ = cg_r (k_scale_system)
-      rc = cgs_persist_launch(h, n, D, dw.Lm, WS(L, cg_r), x0, WS(L, cg_z), WS(L, cg_mail), WS(L, cg_scal), CGS_RTOL, fuse, h->pinned + SFM_PIN_CG1);
+      const PrLaunch pl = {n, D, dw.Lm, WS(L, cg_r), x0, WS(L, cg_z), WS(L, cg_mail), WS(L, cg_scal), CGS_RTOL, fuse, h->pinned + SFM_PIN_CG1, 0};
+      rc = cgs_persist_launch(h, pl);
       if (rc) return rc;
       SFM_HIP(h, hipEventRecord(h->cg_event, h->stream));
       sfm_prof_end(h, SFM_PROF_CHOL);
       launch_backsub(h, p, L, ws, want_q);
       SFM_HIP(h, hipEventSynchronize(h->cg_event));
-      cgs_persist_status(h, h->pinned + SFM_PIN_CG1, p->sharded, &p->cg_iters, &status, &ran);
-      if (!ran && p->sharded) {                       // never switch routes on one rank alone: the same kernel again, then the back-substitution again
-        rc = cgs_persist_retry(h, n, D, dw.Lm, WS(L, cg_r), x0, WS(L, cg_z), WS(L, cg_mail), WS(L, cg_scal), CGS_RTOL, fuse, h->pinned + SFM_PIN_CG1,
-                               &p->cg_iters, &status, &ran);
-        if (rc) return rc;
-        if (status == 0) launch_backsub(h, p, L, ws, want_q);
-      }
+      int relaunched = 0;
+      rc = cgs_persist_verdict(h, pl, p->sharded, &p->cg_iters, &status, &ran, &relaunched);
+      if (rc) return rc;
+      if (relaunched && ran && status == 0) launch_backsub(h, p, L, ws, want_q);      // the first one ran on an unfinished p_c
       if (ran && status == 0) {
         if (warm_on) {
           SFM_HIP(h, hipMemcpyAsync(warm, WS(L, pc), (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
           p->warm_pc_ok = 1; p->warm_alpha = alpha;
         }
         p->cg_state = 1;
+        cgp_note_ok(p->cg_iters - its_before);
         SFM_LAUNCH_CHECK(h, "sfm_ba_schur_solve");
         return SFM_OK;
       }
@@ -2495,8 +2592,10 @@ extern "C" int sfm_ba_schur_solve(sfm_handle h, sfm_ba_problem p, double alpha, 
         p->warm_pc_ok = 1; p->warm_alpha = alpha;
       }
       p->cg_state = 1;
+      cgp_note_ok(p->cg_iters - its_before);
     } else {
       p->cg_fallbacks++;
+      if (p->cg_iters - its_before >= cg_budget && arel > p->cgp_fail_rel) p->cgp_fail_rel = arel;      // out of iterations (not: broken)
     }
     sfm_prof_end(h, SFM_PROF_CHOL);
   }
@@ -2565,7 +2664,8 @@ extern "C" int sfm_ba_finish_solve(sfm_handle h, sfm_ba_problem p, int want_q) {
         DISPATCH_D(D, hipLaunchKernelGGL(k_block_mv<DD>, dim3(cdiv(n, 256)), dim3(256), 0, h->stream, C, WS(L, cg_Minv), WS(L, pc),
                                          WS(L, cg_r), 0, 1.0, WS(L, red_q)));
         PrFuse fuse = {WS(L, cg_Minv), nullptr, nullptr, WS(L, pc), WS(L, red_q), WS(L, scalars), p->host_sc, 1};
-        rc = cgs_persist_launch(h, n, D, dw.Lm, WS(L, cg_r), nullptr, WS(L, cg_z), WS(L, cg_mail), WS(L, cg_scal), CGS_RTOL, fuse, p->host_sc + SFM_SC_COUNT);
+        const PrLaunch pl = {n, D, dw.Lm, WS(L, cg_r), nullptr, WS(L, cg_z), WS(L, cg_mail), WS(L, cg_scal), CGS_RTOL, fuse, p->host_sc + SFM_SC_COUNT, 1};
+        rc = cgs_persist_launch(h, pl);
         if (rc) return rc;
         if (!warm_on) {
           p->cg2_pending = 1;
@@ -2573,12 +2673,9 @@ extern "C" int sfm_ba_finish_solve(sfm_handle h, sfm_ba_problem p, int want_q) {
           return SFM_OK;
         }
         SFM_HIP(h, hipStreamSynchronize(h->stream));
-        cgs_persist_status(h, p->host_sc + SFM_SC_COUNT, p->sharded, &p->cg_iters, &status, &ran);
-        if (!ran && p->sharded) {
-          rc = cgs_persist_retry(h, n, D, dw.Lm, WS(L, cg_r), nullptr, WS(L, cg_z), WS(L, cg_mail), WS(L, cg_scal), CGS_RTOL, fuse,
-                                 p->host_sc + SFM_SC_COUNT, &p->cg_iters, &status, &ran);
-          if (rc) return rc;
-        }
+        int relaunched = 0;
+        rc = cgs_persist_verdict(h, pl, p->sharded, &p->cg_iters, &status, &ran, &relaunched);
+        if (rc) return rc;
         if (ran && status == 0) {
           if (p->warm_pc_ok) {                       // q_c = E^-T x~_2 = -dp_c/dalpha for the next system's start vector
             DISPATCH_D(D, hipLaunchKernelGGL(k_block_mv<DD>, dim3(cdiv(n, 256)), dim3(256), 0, h->stream, C, WS(L, cg_Minv), WS(L, cg_z),
@@ -2885,7 +2982,7 @@ extern "C" int sfm_ba_solve_pcg(sfm_handle h, sfm_ba_problem p, double alpha, in
   const int64_t N = p->n_obs;
   Pcg cg{h, p, L, ws, alpha, rtol, max_iter, reduce, reduce_user, 0};
   if (reduce) p->sharded = 1;          // the formed-S fallback below solves a replicated camera system: same route on every rank
-  SFM_HIP(h, hipMemsetAsync(WS(L, cg_scal), 0, 16 * sizeof(double), h->stream));
+  SFM_HIP(h, hipMemsetAsync(WS(L, cg_scal), 0, 64 * sizeof(double), h->stream));
   // point factors, G, and this rank's part of the right-hand side r = g_c - W C_a^-1 g_p and of the diagonal blocks
   sfm_prof_begin(h, SFM_PROF_BUILD_G);
   hipLaunchKernelGGL(k_point_factor, dim3(cdiv(P, 256)), dim3(256), 0, h->stream, P, alpha, WS(L, Cp), WS(L, gp), WS(L, Linv), WS(L, e));
@@ -3035,15 +3132,14 @@ extern "C" int sfm_ba_read_scalars(sfm_handle h, sfm_ba_problem p, double* out_h
     // synchronisation; if that system did not converge - or its launch was abandoned - the q term is redone from the
     // factorisation now (no exchange between ranks is involved: red_q has been reduced already)
     p->cg2_pending = 0;
-    int status = 1, ran = 0;
-    cgs_persist_status(h, p->host_sc + SFM_SC_COUNT, p->sharded, &p->cg_iters, &status, &ran);
-    if (!ran && p->sharded) {
-      // a sharded solve: the same kernel again (same inputs: r~2 is still in cg_r, S~ in the factor's buffer), never another route
+    int status = 1, ran = 0, relaunched = 0;
+    {
+      // (a relaunch finds the same inputs: r~2 is still in cg_r, S~ in the factor's buffer)
       const int C = p->n_cams, D = p->cam_dim, n = C * D;
       DenseWs dw; dense_ws_carve(WS(L, dense), n, &dw);
       PrFuse fuse = {WS(L, cg_Minv), nullptr, nullptr, WS(L, pc), WS(L, red_q), WS(L, scalars), p->host_sc, 1};
-      rc = cgs_persist_retry(h, n, D, dw.Lm, WS(L, cg_r), nullptr, WS(L, cg_z), WS(L, cg_mail), WS(L, cg_scal), CGS_RTOL, fuse,
-                             p->host_sc + SFM_SC_COUNT, &p->cg_iters, &status, &ran);
+      const PrLaunch pl = {n, D, dw.Lm, WS(L, cg_r), nullptr, WS(L, cg_z), WS(L, cg_mail), WS(L, cg_scal), CGS_RTOL, fuse, p->host_sc + SFM_SC_COUNT, 1};
+      rc = cgs_persist_verdict(h, pl, p->sharded, &p->cg_iters, &status, &ran, &relaunched);
       if (rc) return rc;
     }
     if (!(ran && status == 0)) {

@@ -50,6 +50,14 @@ struct sfm_ba_prob {
   int64_t pcg_fallbacks;
   double pcg_worst_relres;
   double cg_alpha;
+  // Camera CG, SFM_CAMERA_SOLVER_AUTO: what this problem has taught about where the iteration budget runs out (alpha relative
+  // to max diag H): the largest alpha at which CG ran out of iterations (forgotten by 20 % per linearisation), and the last two
+  // converged step systems at different alpha, whose iteration counts give the local exponent of iterations ~ alpha^-s
+  // (measured: s ~ 0.4 on the spatially coherent scene, ~ 0.2 on the random one, falling towards alpha -> 0).  A damped solve at
+  // or below 4 x the failure bound, or for which that power law - with 0.85 s - predicts more than 1.25 x the budget, goes to
+  // the factorisation at once instead of burning the whole budget first (sfm_ba_schur_solve).
+  double cgp_fail_rel, cgp_ok_rel[2];
+  int cgp_ok_its[2];
   // warm start of the camera CG (ba.hip, sfm_ba_schur_solve): p_c / q_c of the previous damped solve of THIS linearisation
   int warm_pc_ok, warm_qc_ok;
   double warm_alpha;

@@ -31,6 +31,7 @@ struct sfm_ctx {
   void* comm;              // ncclComm_t of this handle (comm_rccl.hip), or null
   int comm_owned, comm_ranks, comm_rank;
   int cgs_persist_off;     // set once a persistent CG launch had to be abandoned: per-launch kernel from then on
+  int cgs_xcd_off;         // set once a one-XCD launch of the persistent CG had to be abandoned: device-wide form from then on
 };
 
 // HIP-event bracket around one kernel (or one short kernel sequence) on the handle's stream.

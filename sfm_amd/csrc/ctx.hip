@@ -25,6 +25,7 @@ extern "C" int sfm_create(int device, sfm_handle* out) {
   h->scratch_bytes = 0;
   h->comm = nullptr; h->comm_owned = 0; h->comm_ranks = 0; h->comm_rank = 0;
   h->cgs_persist_off = 0;
+  h->cgs_xcd_off = 0;
   memset(h->prof, 0, sizeof(h->prof));
   if ((e = hipHostMalloc((void**)&h->pinned, SFM_PINNED_DOUBLES * sizeof(double), hipHostMallocDefault)) != hipSuccess) {
     fprintf(stderr, "sfm_create: hipHostMalloc -> %s\n", hipGetErrorString(e));
@@ -108,6 +109,7 @@ extern "C" void sfm_destroy(sfm_handle h) {
 extern "C" int sfm_cgs_persist_enable(sfm_handle h, int enabled) {
   if (!h) return SFM_ERR_ARG;
   h->cgs_persist_off = enabled ? 0 : 1;
+  if (enabled) h->cgs_xcd_off = 0;
   return SFM_OK;
 }
 

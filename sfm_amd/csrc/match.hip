@@ -470,7 +470,7 @@ extern "C" int sfm_debug_match_stamps(unsigned long long* dst, int n_words) {
 #define MATCH_STAMP_END() do {} while (0)
 #endif
 template <int QB, int KS = 4>   // KS = dim / 32: 4 (SIFT), 8 (256 unpacked bits: ORB)
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((QB == 2 && KS == 4) ? 3 : 2, (QB == 2 && KS == 4) ? 3 : 2))) void k_knn2_u8_direct(
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(QB == 8 ? 1 : ((QB == 2 && KS == 4) ? 3 : 2), QB == 8 ? 1 : ((QB == 2 && KS == 4) ? 3 : 2)))) void k_knn2_u8_direct(
     const uint8_t* __restrict__ q, int64_t nq, const uint8_t* __restrict__ xt, int64_t nt, const int* __restrict__ th_t,
     const int* __restrict__ pb_t, const int* __restrict__ qn, int nsplit, int64_t rows_per_split, Cand* __restrict__ part, int* u2g,
     int w_first, int w_second) {
@@ -1011,7 +1011,8 @@ static int match_launch(sfm_ctx* h, int metric, const void* q, int64_t nq_rows, 
   if (wg)   // segments choose their own number of splits: slots a segment does not use must read as "empty" (i = -1)
     SFM_HIP(h, hipMemsetAsync(w.part, 0xFF, (size_t)8 * n_out * 2 * sizeof(Cand), h->stream));
   if (metric == SFM_METRIC_L2_U8) {
-    const bool qb4 = qpw == 512;
+    const bool qb4 = qpw == 512 || qpw == 1024;
+    const bool qb8 = qpw == 1024;          // experiment (SFM_MATCH_QB=8): eight query blocks per wave, ONE wave per SIMD
     const char* d_env = getenv("SFM_MATCH_DIRECT");        // test / tuning knob: "0" = the LDS kernel also for the large case
     // one pair at dim 128: the LDS-free kernel, with 4 query blocks per wave from 28,672 queries on and 2 below (8-20 % faster
     // than the LDS kernel at 2,000 .. 11,000 queries against 4,000 .. 50,000 train rows); the LDS kernel serves the batched
@@ -1049,6 +1050,7 @@ static int match_launch(sfm_ctx* h, int metric, const void* q, int64_t nq_rows, 
       }
       if (direct256) hipLaunchKernelGGL((k_knn2_u8_direct<2, 8>), dim3(grid), dim3(256), 0, h->stream, q8, nq_rows, w.tf, nt_rows, w.th, w.par, w.qn, nsplit, rps, w.part, w.u2, w_first, w_second);
       else if (direct2) hipLaunchKernelGGL((k_knn2_u8_direct<2>), dim3(grid), dim3(256), 0, h->stream, q8, nq_rows, w.tf, nt_rows, w.th, w.par, w.qn, nsplit, rps, w.part, w.u2, w_first, w_second);
+      else if (qb8) hipLaunchKernelGGL((k_knn2_u8_direct<8>), dim3(grid), dim3(256), 0, h->stream, q8, nq_rows, w.tf, nt_rows, w.th, w.par, w.qn, nsplit, rps, w.part, w.u2, 0, 0);
       else hipLaunchKernelGGL((k_knn2_u8_direct<4>), dim3(grid), dim3(256), 0, h->stream, q8, nq_rows, w.tf, nt_rows, w.th, w.par, w.qn, nsplit, rps, w.part, w.u2, w_first, w_second);
     } else if (filter) {
       if (qb4) KNN_LAUNCH(4, 4, true); else if (dim == 256) KNN_LAUNCH(8, 2, true); else if (dim == 128) KNN_LAUNCH(4, 2, true); else if (dim == 64) KNN_LAUNCH(2, 2, true); else KNN_LAUNCH(1, 2, true);

@@ -161,6 +161,11 @@ struct DevBuf {      // scoped device allocation for the construction's temporar
     if (e_ != hipSuccess) { sfm_ba_destroy_problem(p); return sfm_fail(h, SFM_ERR_HIP, #call, hipGetErrorString(e_)); } \
   } while (0)
 
+__global__ void k_pair_uv(int64_t N, const int* __restrict__ cam_obs, const double2* __restrict__ uv_in, double2* __restrict__ uv_out) {
+  const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (q < N) uv_out[cam_obs[q]] = uv_in[q];
+}
+
 extern "C" void sfm_ba_destroy_problem(sfm_ba_problem p) {
   if (!p) return;
   void* owned[] = {p->cam_idx, p->pt_idx, p->uv, p->pt_ptr, p->cam_ptr, p->cam_obs, p->blk_ptr, p->pair_k, p->pair_k2,
@@ -184,6 +189,8 @@ extern "C" int sfm_ba_create_problem(sfm_handle h, const sfm_ba_desc* d, sfm_ba_
     return sfm_fail(h, SFM_ERR_ARG, "sfm_ba_create_problem", "unknown precision");
   if (d->camera_solver < SFM_CAMERA_SOLVER_AUTO || d->camera_solver > SFM_CAMERA_SOLVER_CG)
     return sfm_fail(h, SFM_ERR_ARG, "sfm_ba_create_problem", "unknown camera_solver");
+  if (d->uv_pairing != SFM_UV_AS_GIVEN && d->uv_pairing != SFM_UV_REFERENCE_PAIRING)
+    return sfm_fail(h, SFM_ERR_ARG, "sfm_ba_create_problem", "unknown uv_pairing");
   const int C = d->n_cams, P = d->n_pts;
   const int64_t N = d->n_obs;
   const int64_t n_blk = (int64_t)C * (C + 1) / 2;
@@ -249,6 +256,16 @@ extern "C" int sfm_ba_create_problem(sfm_handle h, const sfm_ba_desc* d, sfm_ba_
   PB_HIP(tmp.alloc(tmp_bytes));
   PB_HIP(rocprim::radix_sort_pairs(tmp.p, tmp_bytes, ck_in.as<unsigned>(), ck_out.as<unsigned>(), cv_in.as<unsigned>(),
                                    (unsigned*)p->cam_obs, (size_t)N, 0, (unsigned)bits_for((uint64_t)C), st));
+
+  // ---- the reference's residual pairing (sfm_reconstruction.py:480-486): the q-th observation of the camera-sorted list
+  // meets the q-th point-major pixel - a scatter through cam_obs (the host's np.argsort + scatter took 55 ms at 1M observations)
+  if (d->uv_pairing == SFM_UV_REFERENCE_PAIRING) {
+    DevBuf uv_in;
+    PB_HIP(uv_in.alloc(N * 16));
+    PB_HIP(hipMemcpyAsync(uv_in.p, p->uv, N * 16, hipMemcpyDeviceToDevice, st));
+    hipLaunchKernelGGL(k_pair_uv, dim3(cdiv(N, 256)), dim3(256), 0, st, N, p->cam_obs, (const double2*)uv_in.p, (double2*)p->uv);
+    PB_HIP(hipStreamSynchronize(st));            // uv_in is released at the end of this scope
+  }
 
   // ---- pairs: count per observation, prefix sum (64-bit), fill, stable sort by block id
   DevBuf cnt, off;

@@ -129,8 +129,11 @@ class BundleAdjustMixin:
             logging.warning("Not enough cameras for bundle adjustment")
             return False
         try:
+            if self.ba_order not in ("reference", "aligned"):
+                raise ValueError(f"unknown order {self.ba_order!r}")
+            # the reference's pairing (order="reference") is applied by the library on the device (SFM_UV_REFERENCE_PAIRING)
             cams, pts, cam_idx, pt_idx, uv, ids = pack_state(
-                self.poses, self.points3D, self.point_tracks, self.K, self.ba_cam_dim, self.ba_order)
+                self.poses, self.points3D, self.point_tracks, self.K, self.ba_cam_dim, "aligned")
             if len(uv) == 0:
                 logging.warning("No points for bundle adjustment")
                 return False
@@ -140,7 +143,8 @@ class BundleAdjustMixin:
         K0 = (self.K[0, 0], self.K[1, 1], self.K[0, 2], self.K[1, 2])
         t_packed = time.perf_counter()
         be = GpuBA(cams, pts, cam_idx, pt_idx, uv, K0, float(self.image_width), float(self.image_height),
-                   device=self.ba_device, precision=self.ba_precision)
+                   device=self.ba_device, precision=self.ba_precision,
+                   uv_pairing="reference" if self.ba_order == "reference" else "as_given")
         x0 = be.x.clone()
         t_built = time.perf_counter()
         try:

@@ -192,7 +192,7 @@ def test_argument_checks_without_gpu():
     need = ctypes.c_int64()
     assert lib.sfm_match_workspace_bytes(0, 50000, 50000, 128, ctypes.byref(need)) == 0 and need.value > 0
     # the ctypes mirrors have the sizes the header's structs have on this ABI
-    assert ctypes.sizeof(_lib.BADesc) == 4 * 4 + 8 + 3 * 8 + 7 * 8 + 2 * 4
+    assert ctypes.sizeof(_lib.BADesc) == 4 * 4 + 8 + 3 * 8 + 7 * 8 + 4 * 4
     assert ctypes.sizeof(_lib.TRFOptions) == 3 * 8 + 4 * 4 + 8 + 2 * 4 and ctypes.sizeof(_lib.TRFResultC) == 2 * 8 + 6 * 4
 
 

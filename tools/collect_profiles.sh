@@ -13,7 +13,7 @@ OUT=$R/gpurun_out/prof_$ROUND/$STAMP
 mkdir -p "$OUT"
 (cd $R && git rev-parse HEAD 2>/dev/null; sha256sum sfm_amd/lib/libsfm_amd.so bench.py) > $OUT/provenance.txt 2>&1
 cd /tmp && export TMPDIR=/tmp
-BA="--no-cpu-baseline --no-matcher --no-d6 --no-mixed --no-pcg --no-dropin --no-driver-rows --no-alt-camera-solver --no-coherent"
+BA="--no-cpu-baseline --no-matcher --no-d6 --no-mixed --no-pcg --no-dropin --no-driver-rows --no-alt-camera-solver --no-coherent --no-reference-order"
 echo "[1/7] bench line (defaults)";           python3 $R/bench.py > $OUT/bench.json 2> $OUT/bench.err || exit 1
 echo "[2/7] kernel trace + stats (BA + matcher)"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt -- python3 $R/bench.py --steps 10 --warmup 5 --no-cpu-baseline --no-d6 --no-mixed --no-pcg --no-dropin --no-driver-rows --no-alt-camera-solver --no-coherent > $OUT/kt.log 2>&1 || exit 1

@@ -1,13 +1,15 @@
 #!/usr/bin/env python3
 """Camera-solve slots (HIP events) against CG iterations per system at cfg4, over a range of alpha: what a system costs
-before its first iteration."""
+before its first iteration.  usage: exp_cg_fixed_cost.py [cams pts]; SFM_CGS_RTOL=1 gives zero iterations, SFM_CGS_XCD=0 the
+device-wide exchange at sizes where the one-XCD form would run."""
 import sys, os
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from sfm_amd import synth
 from sfm_amd.ba import GpuBA
-sc = synth.make_scene(200, 100000, obs_per_point=10, seed=1004, noise_px=0.5, pt_sigma=0.02, cam_sigma=0.002)
+C_, P_ = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 else (200, 100000)
+sc = synth.make_scene(C_, P_, obs_per_point=10, seed=1004, noise_px=0.5, pt_sigma=0.02, cam_sigma=0.002)
 be = GpuBA(sc.cams0, sc.pts0, sc.cam_idx, sc.pt_idx, sc.uv, synth.K_REF)
 _, gnorm, _, hd = be.linearize()
 for mult in (1e-6, 1e-4, 1e-2, 1.0, 1e2, 1e4):
