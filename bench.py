@@ -394,20 +394,20 @@ def main():
         name = ("k_cgs_big_symv" if big_cg else "k_cgs_persist" if persistent else "k_cgs_iter") + \
                ": CG on the block-scaled camera system, n = %d" % n_sys
         if big_cg:
-            # an iteration is one pass over the triangle, and between iterations most of it is served by the 256 MiB Infinity
-            # Cache, for which MI355X_MICROARCH.md states no peak: no `frac` against a roof that does not bind it - the stream
-            # rate and the time share are the figures
+            # an iteration is one pass over the lower triangle of S~ (405 MB at n = 10,000: beyond the 256 MiB Infinity Cache, so
+            # an HBM stream): priced per iteration over the WHOLE slot of the second system (prologue, both kernels of every
+            # iteration, the host's looks at the residual) with the iteration count of this pass
             slot = "trsv" if "trsv" in kernels else "chol"
             sec_it = kernels[slot]["us_per_launch"] * 1e-6 / max(per_system, 1.0)
-            r = {"kernel": name, "bound": "infinity-cache", "achieved": round(tri_bytes / sec_it / 1e9, 1), "peak": None,
-                 "unit": "GB/s", "frac": None, "traffic": None, "work_per_launch": per_system * tri_bytes,
+            ach = tri_bytes / sec_it / 1e9
+            r = {"kernel": name, "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS,
+                 "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None, "work_per_launch": per_system * tri_bytes,
                  "avg_us": kernels[slot]["us_per_launch"], "launches": kernels[slot]["launches"],
-                 "note": "three launches per iteration: k_cgs_big_symv streams the lower triangle of S~ once (%.0f MB: every 128 x "
-                         "128 tile serves both products it takes part in), k_cgs_big_reduce adds the per-tile partial sums in fixed "
-                         "order, k_cgs_big_update runs the recurrences.  `achieved` = triangle bytes / (slot of the second system / "
-                         "its iterations): prologue, all three kernels and the host's looks included.  The triangle does not fit "
-                         "the 256 MiB Infinity Cache whole and is not an HBM stream either; no peak is stated for that level, so "
-                         "no `frac` is given" % (tri_bytes / 1e6)}
+                 "note": "two launches per iteration (Chronopoulos-Gear arrangement of the recurrences): k_cgb_symv forms the new "
+                         "residual on its two 128-entry ranges and streams its tile of the lower triangle of S~ (%.0f MB per iteration: "
+                         "every 128 x 128 tile serves both products it takes part in), k_cgb_reduce adds the per-tile partial sums in "
+                         "fixed order and leaves the two dot products.  `achieved` = triangle bytes / (slot of the second system / its "
+                         "iterations)" % (tri_bytes / 1e6)}
         else:
             r = roof(name, "hbm", (1.0 if persistent else per_system) * n_sys * n_sys * 8.0, 1e9, HBM_PEAK_GBS, "GB/s",
                      "trsv" if "trsv" in kernels else "chol",

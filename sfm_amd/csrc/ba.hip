@@ -932,17 +932,18 @@ __global__ __launch_bounds__(256) void k_schur_assemble(int C, const int* __rest
   // the thread also sums the TRANSPOSED element (col, rr): it then writes the mirror block's entry (rr, col), so that both blocks
   // leave as 80-byte row segments (from the element's own thread the mirror was 100 scattered 8-byte stores per block: worth
   // 70 us of 420 at 1000 cameras, nothing measurable at 200)
+  // ONLY THE LOWER TRIANGLE of S is ever read (k_diag_einv, k_scale_system, the multi-rank exchange sfm_ba_pack_system, the
+  // factorisation: test_upper_triangle_of_S_is_never_read poisons the rest), so an off-diagonal block (c, c2 > c) leaves as its
+  // mirror (c2, c) alone - written from the transposed element, so that it too goes out as 80-byte row segments; the diagonal
+  // block is written whole.  (Writing both triangles was half of this kernel's 0.42 ms at 1000 cameras.)
   const int eT = col * D + rr;
-  double s = 0.0, sT = 0.0;
-  for (int it = item_ptr[blk]; it < item_ptr[blk + 1]; ++it) {
-    s += part[(size_t)it * (D * D) + e];
-    sT += part[(size_t)it * (D * D) + eT];
-  }
+  const int src = (c == c2) ? e : eT;
+  double s = 0.0;
+  for (int it = item_ptr[blk]; it < item_ptr[blk + 1]; ++it) s += part[(size_t)it * (D * D) + src];
   double v = -s;
   if (c == c2) v += B[(size_t)c * D * D + e];
   const int n = C * D;
-  S[(size_t)(c * D + rr) * n + c2 * D + col] = v;
-  if (c != c2) S[(size_t)(c2 * D + rr) * n + c * D + col] = -sT;
+  S[(size_t)(c2 * D + rr) * n + c * D + col] = v;
 }
 
 // out[c][a] = (base ? base[c][a] : 0) - sum_{k in camera c} sum_m G_k[m][a] vec[pt(k)][m]
@@ -1680,6 +1681,61 @@ __global__ __launch_bounds__(128) void k_scale_system(int n, int C, const double
       }
   }
 }
+// The same for the tile-streaming CG (n > 2,048), which reads the 128 x 128 tiles (I, J <= I) of St only - the lower triangle
+// plus, inside the diagonal tiles, the entries above the diagonal: blocks (c, c2) with c2 <= c and the band c < c2 <= c + BAND
+// (a 128-wide tile spans at most 128 / D + 2 cameras).  Every block is read from the lower triangle of S and written ONCE, in
+// its own rows (80-byte row segments): half the bytes of k_scale_system and none of its column-strided mirror writes
+// (0.53 -> 0.2x ms at 1000 cameras).
+template <int D>
+__global__ __launch_bounds__(128) void k_scale_system_lower(int n, int C, const double* __restrict__ S, double alpha,
+                                                            const double* __restrict__ Einv, double* __restrict__ St,
+                                                            const double* __restrict__ rhs, double* __restrict__ rhs_t) {
+  constexpr int BAND = 128 / D + 2;
+  __shared__ double sB[SCALE_NB][D * D], sT[SCALE_NB][D * D], sE2[SCALE_NB][D * D], sE1[D * D];
+  const int c = blockIdx.x, e = threadIdx.x;
+  const int a = e / D, b = e - a * D;
+  const int c2_0 = blockIdx.y * SCALE_NB;
+  if (rhs_t && blockIdx.y == 0 && e < D) {
+    double t = 0.0;
+#pragma unroll
+    for (int k = 0; k < D; ++k) t += Einv[(size_t)c * D * D + e * D + k] * rhs[c * D + k];
+    rhs_t[c * D + e] = t;
+  }
+  if (c2_0 > c + BAND) return;                           // (workgroup-uniform) nothing left of the band's end here
+  const int last = (c + BAND) < (C - 1) ? (c + BAND) : (C - 1);
+  if (e < D * D) {
+    sE1[e] = Einv[(size_t)c * D * D + e];
+#pragma unroll
+    for (int j = 0; j < SCALE_NB; ++j)
+      if (c2_0 + j <= last) {
+        const int c2 = c2_0 + j, row = c * D + a, col = c2 * D + b;
+        sB[j][e] = (col <= row ? S[(size_t)row * n + col] : S[(size_t)col * n + row]) + ((c == c2 && a == b) ? alpha : 0.0);
+        sE2[j][e] = Einv[(size_t)c2 * D * D + e];
+      }
+  }
+  __syncthreads();
+  if (e < D * D) {
+#pragma unroll
+    for (int j = 0; j < SCALE_NB; ++j)
+      if (c2_0 + j <= last) {
+        double t = 0.0;
+#pragma unroll
+        for (int k = 0; k < D; ++k) t += sE1[a * D + k] * sB[j][k * D + b];
+        sT[j][e] = t;
+      }
+  }
+  __syncthreads();
+  if (e < D * D) {
+#pragma unroll
+    for (int j = 0; j < SCALE_NB; ++j)
+      if (c2_0 + j <= last) {
+        double t = 0.0;
+#pragma unroll
+        for (int k = 0; k < D; ++k) t += sT[j][a * D + k] * sE2[j][b * D + k];
+        St[(size_t)(c * D + a) * n + (c2_0 + j) * D + b] = t;
+      }
+  }
+}
 // out_c = Einv_c v_c (transpose 0) or Einv_c^T v_c (transpose 1), optionally negated
 template <int D>
 __global__ void k_block_mv(int C, const double* __restrict__ Einv, const double* __restrict__ v, double* __restrict__ out,
@@ -2304,11 +2360,37 @@ __device__ __forceinline__ double lane_rows16_sum(double (&v)[16], int lane) {
   return t;
 }
 
-// P[J][rows of I] = A_IJ p_J and (J < I) P[I][rows of J] = A_IJ^T p_I for tile t = blockIdx.x of the lower triangle
-__global__ __launch_bounds__(256) void k_cgs_big_symv(int n, const double* __restrict__ St, const double* __restrict__ pvec,
-                                                      double* __restrict__ P, const double* __restrict__ scal) {
-  if (scal[CGS_DONE] != 0.0) return;                // converged (or broken) in an earlier launch of this batch
-  __shared__ double s_pI[SY_T];
+// The recurrences in the Chronopoulos - Gear arrangement, which needs ONE global reduction point per iteration (gamma = r.r and
+// delta = (S~ r).r, both from the product that has just been formed) where the textbook form has two (p.S~p, then r'.r'):
+//     beta = gamma / gamma_prev;  alpha = gamma / (delta - beta gamma / alpha_prev)
+//     p = r + beta p;  s = w + beta s  (= S~ p);  x += alpha p;  r -= alpha s;  w = S~ r
+// So an iteration is TWO launches: the tile kernel - whose prologue sums the per-block dot products of the previous launch (every
+// tile the same 2 nb numbers in the same order: identical scalars everywhere, no broadcast), forms the new r on its own two
+// 128-entry ranges in LDS and multiplies - and the slot reduction, which also leaves the two dot products per block.  The third
+// launch of the first form (a single workgroup running the vector updates over all n entries: 13 us of a ~100-us iteration at
+// n = 10,000, plus its boundary) is gone: the DIAGONAL tile of a range writes that range's r, p, s, x, into the other of two
+// buffer sets (the off-diagonal tiles of the same launch still read the old ones).  Convergence is seen one launch late - the
+// launch whose prologue finds gamma <= rtol^2 gamma_0 copies x out and multiplies nothing.
+// State in the factor's transposed-copy buffer (free on this route): [2][r | p | s | x] | w | dots[2][nbp] | P[nb][n].
+enum { CGB_PAIR = 5 };     // scal[5 + 2 (it & 1)], scal[6 + 2 (it & 1)]: alpha and gamma of launch `it`, read by launch it + 1
+__global__ __launch_bounds__(256) void k_cgb_init(int n, int nbp, const double* __restrict__ rhs, double* __restrict__ vec,
+                                                  double* __restrict__ dots, double* __restrict__ scal) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < n) {
+    vec[i] = rhs[i];                                                                  // r_0 (set 0)
+    vec[(size_t)1 * n + i] = 0.0; vec[(size_t)2 * n + i] = 0.0; vec[(size_t)3 * n + i] = 0.0;     // p, s (times beta = 0 in launch 1), x_0
+  }
+  if (i < 2 * nbp) dots[i] = 0.0;
+  if (i == 0) { scal[CGS_RR0] = 0.0; scal[CGS_RR] = 0.0; scal[CGS_ITER] = 0.0; scal[CGS_DONE] = 0.0; scal[5] = scal[6] = scal[7] = scal[8] = 0.0; }
+}
+__global__ __launch_bounds__(256) void k_cgb_symv(int n, int nb, int nbp, int it, double rtol2, const double* __restrict__ St,
+                                                  double* __restrict__ vec, const double* __restrict__ wv, const double* __restrict__ dots,
+                                                  double* __restrict__ P, double* __restrict__ scal, double* __restrict__ x_out) {
+  // CGS_DONE holds 1 + the index of the launch that saw the end (converged or broken).  Only an EARLIER launch's verdict stops
+  // this one: the tiles of the deciding launch itself all reach the same verdict from the same numbers, and each still has its
+  // range of x to copy out - a tile that started late must not take tile 0's freshly written flag for yesterday's
+  { const double dn = scal[CGS_DONE]; if (dn != 0.0 && dn <= (double)it) return; }
+  __shared__ double s_r[2][SY_T];                   // the new r on the tile's row range (I) and column range (J)
   __shared__ double s_col[4][SY_T];
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   // t -> (I, J), J <= I: I = floor((sqrt(8 t + 1) - 1) / 2), corrected for the rounding of the root
@@ -2318,6 +2400,10 @@ __global__ __launch_bounds__(256) void k_cgs_big_symv(int n, const double* __res
   while (I * (I + 1) / 2 > t) --I;
   const int J = t - I * (I + 1) / 2;
   const int r0 = I * SY_T, c0 = J * SY_T;
+  const size_t N4 = (size_t)4 * n;
+  double* cur = vec + (size_t)((it + 1) & 1) * N4;     // launch it - 1 left r_{it-1}, p_{it-2}, s_{it-2}, x_{it-1} here (it = 0: unused)
+  double* nxt = vec + (size_t)(it & 1) * N4;           // launch 0 reads r_0 from set 0
+  // the matrix loads go first: nothing below depends on them until the products
   const int jc = c0 + 2 * lane;                     // n is even: jc < n implies jc + 1 < n
   const bool col_ok = jc < n;
   double2 a[2][16];
@@ -2328,16 +2414,55 @@ __global__ __launch_bounds__(256) void k_cgs_big_symv(int n, const double* __res
       const int row = r0 + w * 32 + b * 16 + q;
       a[b][q] = (col_ok && row < n) ? *(const double2*)(St + (size_t)row * n + jc) : make_double2(0.0, 0.0);
     }
-  const double pj0 = col_ok ? pvec[jc] : 0.0, pj1 = col_ok ? pvec[jc + 1] : 0.0;
-  if (tid < SY_T) s_pI[tid] = (r0 + tid < n) ? pvec[r0 + tid] : 0.0;
+  const int half = tid >> 7, li = tid & 127;        // threads 0..127: range I, 128..255: range J
+  const int gi = (half ? c0 : r0) + li;
+  if (it == 0) {
+    s_r[half][li] = gi < n ? nxt[gi] : 0.0;
+  } else {
+    // gamma_{it-1}, delta_{it-1}: the per-block parts, summed by every wave of every tile in the same order
+    double g = 0.0, dl = 0.0;
+    for (int bb = lane; bb < nb; bb += 64) { g += dots[bb]; dl += dots[nbp + bb]; }
+    g = wave_sum_all(g); dl = wave_sum_all(dl);
+    const double g_prev = scal[CGB_PAIR + 1 + 2 * ((it + 1) & 1)], a_prev = scal[CGB_PAIR + 2 * ((it + 1) & 1)];
+    const double g0 = it == 1 ? g : scal[CGS_RR0];
+    const bool converged = g <= rtol2 * g0;          // (a zero right-hand side: 0 <= 0, x = 0)
+    const double beta = it == 1 ? 0.0 : g / g_prev;
+    const double den = it == 1 ? dl : dl - beta * g / a_prev;
+    const bool broken = !converged && !(den > 0.0);  // non-positive curvature, or NaN anywhere: S~ is not positive definite
+    if (t == 0 && tid == 0) {
+      if (it == 1) scal[CGS_RR0] = g;
+      scal[CGS_RR] = g; scal[CGS_ITER] = (double)(it - 1);
+      if (converged || broken) scal[CGS_DONE] = (double)(it + 1);
+      if (broken) scal[CGS_FAIL] = 2.0;
+    }
+    if (converged) {                                 // (uniform over the whole grid) x_{it-1} is the answer
+      if (I == J && half == 0 && gi < n) x_out[gi] = cur[(size_t)3 * n + gi];
+      return;
+    }
+    if (broken) return;
+    const double al = g / den;
+    if (t == 0 && tid == 0) { scal[CGB_PAIR + 2 * (it & 1)] = al; scal[CGB_PAIR + 1 + 2 * (it & 1)] = g; }
+    double rn = 0.0;
+    if (gi < n) {
+      const double rr = cur[gi], so = cur[(size_t)2 * n + gi];
+      const double sn = wv[gi] + beta * so;
+      rn = rr - al * sn;
+      if (I == J && half == 0) {                     // the range's diagonal tile keeps the vectors
+        const double pn = rr + beta * cur[(size_t)n + gi];
+        nxt[gi] = rn; nxt[(size_t)n + gi] = pn; nxt[(size_t)2 * n + gi] = sn; nxt[(size_t)3 * n + gi] = cur[(size_t)3 * n + gi] + al * pn;
+      }
+    }
+    s_r[half][li] = rn;
+  }
   __syncthreads();
+  const double pj0 = col_ok ? s_r[1][2 * lane] : 0.0, pj1 = col_ok ? s_r[1][2 * lane + 1] : 0.0;
   double cs0 = 0.0, cs1 = 0.0;
 #pragma unroll
   for (int b = 0; b < 2; ++b) {
     double v[16];
 #pragma unroll
     for (int q = 0; q < 16; ++q) {
-      const double pi = s_pI[w * 32 + b * 16 + q];
+      const double pi = s_r[0][w * 32 + b * 16 + q];
       v[q] = a[b][q].x * pj0 + a[b][q].y * pj1;
       cs0 += a[b][q].x * pi; cs1 += a[b][q].y * pi;
     }
@@ -2351,54 +2476,25 @@ __global__ __launch_bounds__(256) void k_cgs_big_symv(int n, const double* __res
     if (tid < SY_T && c0 + tid < n) P[(size_t)I * n + c0 + tid] = (s_col[0][tid] + s_col[1][tid]) + (s_col[2][tid] + s_col[3][tid]);
   }
 }
-// S~p = sum over the nb slots (fixed order); dots[B] = the block's part of p . S~p.  One workgroup of 128 per block of 128 entries.
-__global__ __launch_bounds__(128) void k_cgs_big_reduce(int n, int nb, const double* __restrict__ P, const double* __restrict__ pvec,
-                                                        double* __restrict__ Ap, double* __restrict__ dots, const double* __restrict__ scal) {
+// w = S~ r = sum over the nb slots (fixed order); the block's parts of gamma = r.r and delta = w.r.  One workgroup of 128 per
+// block of 128 entries.  r is the one launch `it` of the tile kernel has just formed (set it & 1).
+__global__ __launch_bounds__(128) void k_cgb_reduce(int n, int nb, int nbp, int it, const double* __restrict__ P, const double* __restrict__ vec,
+                                                    double* __restrict__ wv, double* __restrict__ dots, const double* __restrict__ scal) {
   if (scal[CGS_DONE] != 0.0) return;
-  __shared__ double s_w[2];
+  __shared__ double s_w[2][2];
   const int i = (int)blockIdx.x * SY_T + threadIdx.x;
-  double s = 0.0;
+  const double* r = vec + (size_t)(it & 1) * 4 * n;
+  double sum = 0.0, ri = 0.0;
   if (i < n) {
 #pragma unroll 8
-    for (int k = 0; k < nb; ++k) s += P[(size_t)k * n + i];
-    Ap[i] = s;
+    for (int k = 0; k < nb; ++k) sum += P[(size_t)k * n + i];
+    wv[i] = sum;
+    ri = r[i];
   }
-  double d = wave_sum_all(i < n ? s * pvec[i] : 0.0);
-  if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = d;
+  const double g = wave_sum_all(ri * ri), d = wave_sum_all(sum * ri);
+  if ((threadIdx.x & 63) == 0) { s_w[0][threadIdx.x >> 6] = g; s_w[1][threadIdx.x >> 6] = d; }
   __syncthreads();
-  if (threadIdx.x == 0) dots[blockIdx.x] = s_w[0] + s_w[1];
-}
-__device__ __forceinline__ double block_sum1024(double v, double* s);
-// alpha = rr / p.S~p;  x += alpha p;  r -= alpha S~p;  beta = rr' / rr;  p = r + beta p.  ONE workgroup.
-__global__ __launch_bounds__(1024) void k_cgs_big_update(int n, int nb, int it, double rtol2, double* __restrict__ r, double* __restrict__ pvec,
-                                                         const double* __restrict__ Ap, const double* __restrict__ dots,
-                                                         double* __restrict__ x, double* __restrict__ scal) {
-  __shared__ double s_red[17];
-  const int tid = threadIdx.x;
-  const bool stop = scal[CGS_DONE] != 0.0;
-  const double rr_old = scal[CGS_RR], rr0 = scal[CGS_RR0];
-  double d = 0.0;
-  for (int b = tid; b < nb; b += 1024) d += dots[b];
-  const double pAp = block_sum1024(d, s_red);       // (its barriers also order the reads above before the writes below)
-  if (stop) return;
-  if (!(pAp > 0.0)) {                                // non-positive curvature (or NaN): S~ is not positive definite
-    if (tid == 0) { scal[CGS_FAIL] = 2.0; scal[CGS_DONE] = 1.0; }
-    return;
-  }
-  const double al = rr_old / pAp;
-  double rr = 0.0;
-  for (int i = tid; i < n; i += 1024) {
-    x[i] += al * pvec[i];
-    const double rn = r[i] - al * Ap[i];
-    r[i] = rn; rr += rn * rn;
-  }
-  const double rr_new = block_sum1024(rr, s_red);
-  const double beta = rr_new / rr_old;
-  for (int i = tid; i < n; i += 1024) pvec[i] = r[i] + beta * pvec[i];
-  if (tid == 0) {
-    scal[CGS_RR] = rr_new; scal[CGS_ITER] = (double)(it + 1);
-    if (rr_new <= rtol2 * rr0) scal[CGS_DONE] = 1.0;
-  }
+  if (threadIdx.x == 0) { dots[blockIdx.x] = s_w[0][0] + s_w[0][1]; dots[nbp + blockIdx.x] = s_w[1][0] + s_w[1][1]; }
 }
 
 // Which launch-per-iteration CG a system of n unknowns takes when the persistent kernel does not apply: the tile-streaming
@@ -2415,34 +2511,38 @@ static bool cgs_use_big(int n) {
   return n >= from;
 }
 static bool cgs_possible(int n) { return (n & 1) == 0 && (n <= CGS_MAX_N || cgs_use_big(n)); }
+// its_hint: iterations the last converged system of this problem took (0: unknown) - the first batch of launches is sized for it
+// (a batch is enqueued blind and the host looks at the residual behind it; launches past convergence return at once but still
+// cost ~3 us each: at 14 iterations per system, 30 of the fixed first batch of 72 launches were such)
 static int cgs_solve_big(sfm_ctx* h, int n, const double* St, const double* rhs_t, double* x_t, double* buf, double* scal,
-                         double rtol, int* iters_out, int* status) {
+                         double rtol, int* iters_out, int* status, int its_hint = 0) {
   const double rtol2 = rtol * rtol;
   *status = 1;
-  const int nb = (int)cdiv(n, SY_T);
+  const int nb = (int)cdiv(n, SY_T), nbp = (nb + 127) & ~127;
   const unsigned n_tiles = (unsigned)((int64_t)nb * (nb + 1) / 2);
-  double *r = buf, *pv = buf + n, *Ap = buf + 2 * (size_t)n, *dots = buf + 3 * (size_t)n, *P = dots + ((nb + 127) & ~127);
-  hipLaunchKernelGGL(k_cgs_init, dim3(1), dim3(256), 0, h->stream, n, rhs_t, x_t, r, pv, scal);
+  double *vec = buf, *wv = buf + 8 * (size_t)n, *dots = wv + n, *P = dots + 2 * (size_t)nbp;
+  hipLaunchKernelGGL(k_cgb_init, dim3(cdiv(n > 2 * nbp ? n : 2 * nbp, 256)), dim3(256), 0, h->stream, n, nbp, rhs_t, vec, dots, scal);
+  // launch `it` forms r_it (it >= 1: from the dot products launch it - 1 left) and multiplies; launch it = k + 1 is the one that
+  // sees iterate k converged and copies it out, so a system of k iterations takes k + 2 launch pairs
   int it = 0;
-  int batch = 24;
-  while (it < CGS_BIG_MAX_ITER) {
-    for (int b = 0; b < batch && it < CGS_BIG_MAX_ITER; ++b, ++it) {
-      hipLaunchKernelGGL(k_cgs_big_symv, dim3(n_tiles), dim3(256), 0, h->stream, n, St, pv, P, scal);
-      hipLaunchKernelGGL(k_cgs_big_reduce, dim3(nb), dim3(128), 0, h->stream, n, nb, P, pv, Ap, dots, scal);
-      hipLaunchKernelGGL(k_cgs_big_update, dim3(1), dim3(1024), 0, h->stream, n, nb, it, rtol2, r, pv, Ap, dots, x_t, scal);
+  int batch = its_hint > 0 ? (its_hint + 4 > 48 ? 48 : its_hint + 4) : 24;
+  while (it < CGS_BIG_MAX_ITER + 2) {
+    for (int b = 0; b < batch && it < CGS_BIG_MAX_ITER + 2; ++b, ++it) {
+      hipLaunchKernelGGL(k_cgb_symv, dim3(n_tiles), dim3(256), 0, h->stream, n, nb, nbp, it, rtol2, St, vec, wv, dots, P, scal, x_t);
+      hipLaunchKernelGGL(k_cgb_reduce, dim3(nb), dim3(128), 0, h->stream, n, nb, nbp, it, P, vec, wv, dots, scal);
     }
     SFM_HIP(h, hipMemcpyAsync(h->pinned, scal, 8 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
     SFM_HIP(h, hipStreamSynchronize(h->stream));
     if (h->pinned[CGS_FAIL] != 0.0) break;
+    if (h->pinned[CGS_DONE] != 0.0) { *status = 0; break; }          // (the launch that saw it has copied x out)
     const double rr = h->pinned[CGS_RR], rr0 = h->pinned[CGS_RR0];
-    if (rr <= rtol2 * rr0) { *status = 0; break; }
     // next look where the residual should be small enough, from the average rate so far (as cgs_solve)
     const double done_its = h->pinned[CGS_ITER] > 1.0 ? h->pinned[CGS_ITER] : 1.0;
-    const double rate = std::log(rr / rr0) / done_its;
+    const double rate = rr0 > 0.0 ? std::log(rr / rr0) / done_its : 0.0;
     batch = 8;
     if (rate < -1e-3 && rr > 0.0) {
       const double need = std::log(rtol2 * rr0 / rr) / rate;
-      batch = need < 2.0 ? 2 : (need > 48.0 ? 48 : (int)need + 2);
+      batch = need < 2.0 ? 3 : (need > 48.0 ? 48 : (int)need + 3);
     }
   }
   *iters_out += (int)h->pinned[CGS_ITER];
@@ -2531,8 +2631,12 @@ extern "C" int sfm_ba_schur_solve(sfm_handle h, sfm_ba_problem p, double alpha, 
     p->cg_scal_clean = 0;
     DISPATCH_D(D, {
       hipLaunchKernelGGL(k_diag_einv<DD>, dim3(cdiv(C, 64)), dim3(64), 0, h->stream, C, S, n, alpha, WS(L, cg_Minv), WS(L, cg_M), WS(L, cg_scal));
-      hipLaunchKernelGGL(k_scale_system<DD>, dim3(C, cdiv(C, SCALE_NB)), dim3(128), 0, h->stream, n, C, S, alpha, WS(L, cg_Minv), dw.Lm,
-                         S + (size_t)n * n, WS(L, cg_r));
+      if (cgs_use_big(n) && !cgs_persist_usable(h, n))   // the tile-streaming CG reads the lower triangle (+ the diagonal tiles) only
+        hipLaunchKernelGGL(k_scale_system_lower<DD>, dim3(C, cdiv(C, SCALE_NB)), dim3(128), 0, h->stream, n, C, S, alpha, WS(L, cg_Minv), dw.Lm,
+                           S + (size_t)n * n, WS(L, cg_r));
+      else
+        hipLaunchKernelGGL(k_scale_system<DD>, dim3(C, cdiv(C, SCALE_NB)), dim3(128), 0, h->stream, n, C, S, alpha, WS(L, cg_Minv), dw.Lm,
+                           S + (size_t)n * n, WS(L, cg_r));
     });
     int status = 1, ran = 0;
     // Warm start (persistent kernel only; SFM_CGS_WARM=1, off by default: measured 13 % fewer iterations and no time saved).
@@ -2581,7 +2685,10 @@ extern "C" int sfm_ba_schur_solve(sfm_handle h, sfm_ba_problem p, double alpha, 
     }
     if (!ran) {                                       // launch per iteration, with the scaling of r and of the solution as kernels of their own
       DISPATCH_D(D, hipLaunchKernelGGL(k_block_mv<DD>, dim3(cdiv(n, 256)), dim3(256), 0, h->stream, C, WS(L, cg_Minv), S + (size_t)n * n, WS(L, cg_r), 0, 1.0));
-      rc = (cgs_use_big(n) ? cgs_solve_big : cgs_solve)(h, n, dw.Lm, WS(L, cg_r), WS(L, cg_z), dw.LmT, WS(L, cg_scal), CGS_RTOL, &p->cg_iters, &status); if (rc) return rc;
+      if (cgs_use_big(n)) rc = cgs_solve_big(h, n, dw.Lm, WS(L, cg_r), WS(L, cg_z), dw.LmT, WS(L, cg_scal), CGS_RTOL, &p->cg_iters, &status, p->cgp_ok_its[0]);
+      else rc = cgs_solve(h, n, dw.Lm, WS(L, cg_r), WS(L, cg_z), dw.LmT, WS(L, cg_scal), CGS_RTOL, &p->cg_iters, &status);
+      if (rc) return rc;
+      p->cg_its_sys1 = p->cg_iters - its_before;
       if (status == 0)
         DISPATCH_D(D, hipLaunchKernelGGL(k_block_mv<DD>, dim3(cdiv(n, 256)), dim3(256), 0, h->stream, C, WS(L, cg_Minv), WS(L, cg_z),
                                          WS(L, pc), 1, -1.0));                      // p_c = -E^-T x~
@@ -2691,7 +2798,10 @@ extern "C" int sfm_ba_finish_solve(sfm_handle h, sfm_ba_problem p, int want_q) {
         hipLaunchKernelGGL(k_add_vec, dim3(cdiv(n, 256)), dim3(256), 0, h->stream, WS(L, pc), WS(L, red_q), WS(L, tvec), n);
         DISPATCH_D(D, hipLaunchKernelGGL(k_block_mv<DD>, dim3(cdiv(n, 256)), dim3(256), 0, h->stream, C, WS(L, cg_Minv), WS(L, tvec),
                                          WS(L, cg_r), 0, 1.0));
-        rc = (cgs_use_big(n) ? cgs_solve_big : cgs_solve)(h, n, dw.Lm, WS(L, cg_r), WS(L, cg_z), dw.LmT, WS(L, cg_scal), CGS_RTOL, &p->cg_iters, &status); if (rc) return rc;
+        // (the q system of a damped solve takes about as many iterations as its step system just did)
+        if (cgs_use_big(n)) rc = cgs_solve_big(h, n, dw.Lm, WS(L, cg_r), WS(L, cg_z), dw.LmT, WS(L, cg_scal), CGS_RTOL, &p->cg_iters, &status, p->cg_its_sys1);
+        else rc = cgs_solve(h, n, dw.Lm, WS(L, cg_r), WS(L, cg_z), dw.LmT, WS(L, cg_scal), CGS_RTOL, &p->cg_iters, &status);
+        if (rc) return rc;
         if (status == 0)
           hipLaunchKernelGGL(k_dot, dim3(1), dim3(1024), 0, h->stream, n, WS(L, cg_r), WS(L, cg_z), WS(L, cg_scal) + 8);
       }

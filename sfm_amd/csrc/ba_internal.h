@@ -58,6 +58,7 @@ struct sfm_ba_prob {
   // the factorisation at once instead of burning the whole budget first (sfm_ba_schur_solve).
   double cgp_fail_rel, cgp_ok_rel[2];
   int cgp_ok_its[2];
+  int cg_its_sys1;           // iterations of the step system of the current damped solve (launch-per-iteration routes)
   // warm start of the camera CG (ba.hip, sfm_ba_schur_solve): p_c / q_c of the previous damped solve of THIS linearisation
   int warm_pc_ok, warm_qc_ok;
   double warm_alpha;
