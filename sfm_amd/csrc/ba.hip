@@ -679,7 +679,7 @@ __global__ __launch_bounds__(256) void k_build_G(int64_t N, const int* __restric
 // 16 gathers of 8 pairs are in flight together.  k_schur_assemble then sums the items of each block in
 // order (bitwise reproducible), adds B_c on the diagonal and writes the block and its mirror.
 // build-time tuning knobs of the gather: waves per SIMD the register budget is cut for, and 16-byte chunk loads in flight per
-// operand and wave.  Measured (round 3, tools/exp_schur_occupancy.sh, tools/exp_coherent_occupancy.sh; us per launch):
+// operand and wave.  Measured (round 3, tools/exp_schur_occupancy.sh; us per launch):
 //   (waves, loads)     d = 10 random   d = 6 random   d = 10 coherent scene
 //   (5, 8)                  312             349              335
 //   (6, 6)                  312             325              342

@@ -6,7 +6,7 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/${1:-exp_schur}
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-BA="--no-cpu-baseline --no-matcher --no-d6 --no-mixed --no-pcg --no-dropin --no-driver-rows --no-alt-camera-solver"
+BA="--no-cpu-baseline --no-matcher --no-d6 --no-mixed --no-pcg --no-dropin --no-driver-rows --no-alt-camera-solver --no-reference-order"
 for grp in mod8 contig; do for pad in 0 1; do
   echo "== bench group=$grp pad=$pad"
   SFM_XCD_GROUP=$grp SFM_G_PAD=$pad timeout -k 10 200 python3 $R/bench.py $BA > $OUT/bench_${grp}_pad${pad}.json 2> $OUT/bench_${grp}_pad${pad}.err || exit 1
