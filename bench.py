@@ -779,6 +779,29 @@ def main():
                                 "lower triangle of [S | r]; small exchanges priced at the latency term alone"},
             "projected": proj,
             "reading": "strong scaling of a fixed scene: only the first term shrinks with N; DESIGN.md section 5"}
+        if ba_pcg and ba_pcg.get("pcg_iterations_timed_pass"):
+            # the S-free route (sfm_ba_solve_pcg): nothing n x n is formed or exchanged; per PCG iteration two rank-local passes over
+            # G (they shard with the points) and ONE all-reduce of an n-vector.  Measured here on one rank: iterations and the time
+            # of the two solve slots of the profiled pass; projected: the local part / N but never below a floor of launch-bound
+            # time (five small launches per iteration), plus the all-reduce
+            kp = ba_pcg["kernels_us"]
+            n_sys_pcg = 2 * profd["damped_solves"] - (profd["damped_solves"] - kernels.get("trsv", {}).get("launches", 0))
+            its_pcg = ba_pcg["pcg_iterations_timed_pass"]
+            solve_us = (kp.get("chol", 0.0) * profd["damped_solves"] + kp.get("trsv", 0.0) * kernels.get("trsv", {}).get("launches", 0))
+            it_us = solve_us / max(its_pcg, 1)
+            FLOOR_US = 30.0
+            other_pcg = ba_pcg["ms_per_step"] * 1e3 - solve_us / args.steps          # linearisation, G, back-substitution, trial: shards
+            projp = {}
+            for N in (2, 4, 8):
+                per_it = max(it_us / N, FLOOR_US) + ar_us(n_sys * 8, N)
+                t = other_pcg / N + its_pcg / args.steps * per_it
+                projp[str(N)] = {"us_per_outer_iteration": round(t, 1), "speedup_vs_one_gpu_dense_route": round(step_us / t, 2)}
+            scaling_model["s_free_route"] = {
+                "measured_one_rank": {"pcg_iterations_per_outer_iteration": round(its_pcg / args.steps, 1),
+                                      "us_per_pcg_iteration": round(it_us, 1), "systems": n_sys_pcg,
+                                      "us_per_outer_iteration": round(ba_pcg["ms_per_step"] * 1e3, 1)},
+                "assumed": {"launch_bound_floor_us_per_iteration": FLOOR_US, "exchanged_per_iteration_bytes": n_sys * 8},
+                "projected": projp}
 
     rccl_seen = None
     if getattr(comm, "in_library", False):

@@ -455,6 +455,9 @@ constexpr int MATCH_W_FIRST = 135, MATCH_W_SECOND = 100;
 #ifndef SFM_MATCH_STAMPS
 #define SFM_MATCH_STAMPS 0
 #endif
+#ifndef SFM_MATCH_TH_AHEAD
+#define SFM_MATCH_TH_AHEAD 1
+#endif
 #if SFM_MATCH_STAMPS
 __device__ unsigned long long g_match_stamps[4 * 4096 * 4];
 extern "C" int sfm_debug_match_stamps(unsigned long long* dst, int n_words) {
@@ -470,7 +473,7 @@ extern "C" int sfm_debug_match_stamps(unsigned long long* dst, int n_words) {
 #define MATCH_STAMP_END() do {} while (0)
 #endif
 template <int QB, int KS = 4>   // KS = dim / 32: 4 (SIFT), 8 (256 unpacked bits: ORB)
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(QB == 8 ? 1 : ((QB == 2 && KS == 4) ? 3 : 2), QB == 8 ? 1 : ((QB == 2 && KS == 4) ? 3 : 2)))) void k_knn2_u8_direct(
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((QB == 2 && KS == 4) ? 3 : 2, (QB == 2 && KS == 4) ? 3 : 2))) void k_knn2_u8_direct(
     const uint8_t* __restrict__ q, int64_t nq, const uint8_t* __restrict__ xt, int64_t nt, const int* __restrict__ th_t,
     const int* __restrict__ pb_t, const int* __restrict__ qn, int nsplit, int64_t rows_per_split, Cand* __restrict__ part, int* u2g,
     int w_first, int w_second) {
@@ -561,8 +564,21 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(QB == 8 ? 1
     o[12] = QUAD_BCAST(qv.x, 3); o[13] = QUAD_BCAST(qv.y, 3); o[14] = QUAD_BCAST(qv.z, 3); o[15] = QUAD_BCAST(qv.w, 3);
     return o;
   };
+  // the same, four registers at a time (piece g = registers 4 g .. 4 g + 3 = the quarter of quad lane g)
+  auto spread_th_piece = [&](v16i& o, const int4& qv, int g) {
+    switch (g) {
+      case 0: o[0] = QUAD_BCAST(qv.x, 0); o[1] = QUAD_BCAST(qv.y, 0); o[2] = QUAD_BCAST(qv.z, 0); o[3] = QUAD_BCAST(qv.w, 0); break;
+      case 1: o[4] = QUAD_BCAST(qv.x, 1); o[5] = QUAD_BCAST(qv.y, 1); o[6] = QUAD_BCAST(qv.z, 1); o[7] = QUAD_BCAST(qv.w, 1); break;
+      case 2: o[8] = QUAD_BCAST(qv.x, 2); o[9] = QUAD_BCAST(qv.y, 2); o[10] = QUAD_BCAST(qv.z, 2); o[11] = QUAD_BCAST(qv.w, 2); break;
+      default: o[12] = QUAD_BCAST(qv.x, 3); o[13] = QUAD_BCAST(qv.y, 3); o[14] = QUAD_BCAST(qv.z, 3); o[15] = QUAD_BCAST(qv.w, 3); break;
+    }
+  };
 #undef QUAD_BCAST
   auto load_tile = [&](int64_t tile, int set) {
+#if SFM_MATCH_TH_AHEAD
+    // (first: it is used one step before the operands - see th_carry - and loads return in order)
+    thq[set] = *(const int4*)(th_t + (tile * 2 + half) * 16 + 4 * (lane & 3));
+#endif
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) at[set][ks] = *(const v4i*)(xt + ((tile * KS + ks) * 64 + lane) * 16);
     // the 16 start values of a half-wave: every lane fetches ONE quarter (the quarter its position in its quad names), the
@@ -570,7 +586,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(QB == 8 ? 1
     // every lane all 16 directly - and cost the CU's single texture-address path 64 cycles per wave and tile instead of 16;
     // with 13 vector loads per tile that path, not the matrix unit, bounded the kernel (8 waves x 13 x 16 cycles against
     // 1,024 cycles of MFMAs per tile and SIMD).
+#if !SFM_MATCH_TH_AHEAD
     thq[set] = *(const int4*)(th_t + (tile * 2 + half) * 16 + 4 * (lane & 3));
+#endif
     pb[set] = pb_t[tile * 2 + half];
   };
   // The ranking of a step's accumulators (see k_knn2_u8) is issued in the gaps between the MFMAs of the NEXT step, across
@@ -651,6 +669,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(QB == 8 ? 1
     }
   };
   v16i acc[2];
+#if SFM_MATCH_TH_AHEAD
+  v16i th_carry;
+#endif
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc[1][r] = SENT_TH;         // "previous step" of the first one: padding rows, ranked and ignored
   pb[1] = 0;
@@ -679,7 +700,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(QB == 8 ? 1
     }
     load_tile(tile0 + (t + 1 < n_tiles ? t + 1 : t), pset);
     const int wb_prev = (((t - 1) & 7) << 5) | (4 * half), wb_cur = ((t & 7) << 5) | (4 * half);
+#if SFM_MATCH_TH_AHEAD
+    // The 16 DPP moves that spread a tile's start values used to stand between the last MFMA of one tile and the first of the
+    // next (the first MFMA takes them as its C operand).  They now run in the MFMA gaps of the PREVIOUS tile's last step, four
+    // per gap, into th_carry - whose registers are free by then (the last step has copied its start values already).
+    const v16i th = th_carry;
+#else
     const v16i th = spread_th(thq[set]);
+#endif
 #pragma unroll
     for (int qb = 0; qb < QB; ++qb) {
       const v16i& prev = acc[(qb - 1) & 1];                // the very first step ranks the padding values acc[1] starts with
@@ -689,6 +717,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(QB == 8 ? 1
         acc[qb & 1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(at[set][ks], bq[qb][ks], acc[qb & 1], 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
         if (ks < 4) rank_group_min(prev, ks);              // the four group minima of the previous step: one per MFMA gap
+#if SFM_MATCH_TH_AHEAD
+        if (qb == QB - 1 && ks < 4) spread_th_piece(th_carry, thq[pset], ks);
+#endif
         __builtin_amdgcn_sched_barrier(0);
       }
       if (qb > 0) rank_finish(prev, qb - 1, pb[set], wb_cur);
@@ -699,6 +730,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(QB == 8 ? 1
     }
   };
   if (n_tiles > 0) load_tile(tile0, 0);
+#if SFM_MATCH_TH_AHEAD
+  th_carry = spread_th(thq[0]);
+#endif
   // pairs of tiles in a loop with ONE exit, an odd last tile after it: with `if (t + 1 >= n_tiles) break;` between the two
   // halves of the body the compiler kept the running keys of every query block in two register homes, one per exit, and
   // copied them from one to the other after every step (4 of the ~16 vector instructions of a step nothing is ranked in)
@@ -1011,8 +1045,7 @@ static int match_launch(sfm_ctx* h, int metric, const void* q, int64_t nq_rows, 
   if (wg)   // segments choose their own number of splits: slots a segment does not use must read as "empty" (i = -1)
     SFM_HIP(h, hipMemsetAsync(w.part, 0xFF, (size_t)8 * n_out * 2 * sizeof(Cand), h->stream));
   if (metric == SFM_METRIC_L2_U8) {
-    const bool qb4 = qpw == 512 || qpw == 1024;
-    const bool qb8 = qpw == 1024;          // experiment (SFM_MATCH_QB=8): eight query blocks per wave, ONE wave per SIMD
+    const bool qb4 = qpw == 512;
     const char* d_env = getenv("SFM_MATCH_DIRECT");        // test / tuning knob: "0" = the LDS kernel also for the large case
     // one pair at dim 128: the LDS-free kernel, with 4 query blocks per wave from 28,672 queries on and 2 below (8-20 % faster
     // than the LDS kernel at 2,000 .. 11,000 queries against 4,000 .. 50,000 train rows); the LDS kernel serves the batched
@@ -1050,7 +1083,6 @@ static int match_launch(sfm_ctx* h, int metric, const void* q, int64_t nq_rows, 
       }
       if (direct256) hipLaunchKernelGGL((k_knn2_u8_direct<2, 8>), dim3(grid), dim3(256), 0, h->stream, q8, nq_rows, w.tf, nt_rows, w.th, w.par, w.qn, nsplit, rps, w.part, w.u2, w_first, w_second);
       else if (direct2) hipLaunchKernelGGL((k_knn2_u8_direct<2>), dim3(grid), dim3(256), 0, h->stream, q8, nq_rows, w.tf, nt_rows, w.th, w.par, w.qn, nsplit, rps, w.part, w.u2, w_first, w_second);
-      else if (qb8) hipLaunchKernelGGL((k_knn2_u8_direct<8>), dim3(grid), dim3(256), 0, h->stream, q8, nq_rows, w.tf, nt_rows, w.th, w.par, w.qn, nsplit, rps, w.part, w.u2, 0, 0);
       else hipLaunchKernelGGL((k_knn2_u8_direct<4>), dim3(grid), dim3(256), 0, h->stream, q8, nq_rows, w.tf, nt_rows, w.th, w.par, w.qn, nsplit, rps, w.part, w.u2, w_first, w_second);
     } else if (filter) {
       if (qb4) KNN_LAUNCH(4, 4, true); else if (dim == 256) KNN_LAUNCH(8, 2, true); else if (dim == 128) KNN_LAUNCH(4, 2, true); else if (dim == 64) KNN_LAUNCH(2, 2, true); else KNN_LAUNCH(1, 2, true);

@@ -56,8 +56,7 @@ static inline int64_t match_qpw(int metric, int dim, int64_t nq, bool batched) {
   // measured crossover (round 3, 20 calls each, us per call, 4 blocks / 2 blocks per wave): 12,288 queries 82 / 74,
   // 16,384: 98 / 89, 24,576: 166 / 146 (square sets; against 50,000 train rows 267 / 260), 32,768: 223 / 228 (301 / 317),
   // 40,960: 312 / 332, 50,000: 418 / 451 - two blocks (three waves per SIMD) win up to ~28k queries
-  const bool qb4 = !batched && metric == SFM_METRIC_L2_U8 && dim == 128 && (qb_env ? (qb_env[0] == '4' || qb_env[0] == '8') : nq >= 28672);
-  if (qb4 && qb_env && qb_env[0] == '8') return 1024;       // experiment: eight query blocks per wave (k_knn2_u8_direct<8>)
+  const bool qb4 = !batched && metric == SFM_METRIC_L2_U8 && dim == 128 && (qb_env ? qb_env[0] == '4' : nq >= 28672);
   return qb4 ? 512 : 256;
 }
 

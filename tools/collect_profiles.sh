@@ -32,8 +32,8 @@ rocprofv3 --pmc SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LD
 echo "[6/7] cfg3 bench line (50 cams / 20k pts / 200k obs)"
 python3 $R/bench.py --cams 50 --pts 20000 --no-matcher --no-driver-rows --no-dropin --no-coherent > $OUT/bench_cfg3.json 2> $OUT/bench_cfg3.err || exit 1
 echo "[7/7] cfg5 bench line (1000 cams / 500k pts / 5M obs) + kernel stats"
-python3 $R/bench.py --cams 1000 --pts 500000 --steps 3 --warmup 1 --no-matcher --no-driver-rows --no-dropin --no-d6 --no-cpu-baseline --no-coherent > $OUT/bench_cfg5.json 2> $OUT/bench_cfg5.err || exit 1
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt5 -- python3 $R/bench.py --cams 1000 --pts 500000 --steps 2 --warmup 1 --no-matcher --no-driver-rows --no-dropin --no-d6 --no-mixed --no-pcg --no-cpu-baseline --no-alt-camera-solver --no-coherent > $OUT/kt5.log 2>&1 || exit 1
+python3 $R/bench.py --cams 1000 --pts 500000 --steps 3 --warmup 1 --no-matcher --no-driver-rows --no-dropin --no-d6 --no-cpu-baseline --no-coherent --no-reference-order > $OUT/bench_cfg5.json 2> $OUT/bench_cfg5.err || exit 1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt5 -- python3 $R/bench.py --cams 1000 --pts 500000 --steps 2 --warmup 1 --no-matcher --no-driver-rows --no-dropin --no-d6 --no-mixed --no-pcg --no-cpu-baseline --no-alt-camera-solver --no-coherent --no-reference-order > $OUT/kt5.log 2>&1 || exit 1
 # keep only what the summariser reads (the raw traces are large)
 find $OUT -name "*kernel_trace.csv" -size +20M -delete
 du -sh $OUT
