@@ -560,7 +560,11 @@ __global__ __launch_bounds__(256) void k_finish_linearize(int n, const double* _
 // L_j L_j^T = C_j + alpha I ; stores M = L_j^-1 (lower, packed m00 m10 m11 m20 m21 m22) and e_j = M g_pj.
 __global__ void k_point_factor(int P, double alpha, const double* __restrict__ Cp,
                                const double* __restrict__ gp, double* __restrict__ Linv,
-                               double* __restrict__ e) {
+                               double* __restrict__ e, double* __restrict__ cg_scal = nullptr) {
+  // the status and ticket words of the camera CG that follows start from zero: cleared HERE, by the first kernel of
+  // sfm_ba_schur_build, instead of by a memset between two kernels of the chain (a fill kernel of its own, ~5 us with its
+  // boundaries) - and before k_schur_assemble, whose diagonal-block workgroups may RAISE the failure word
+  if (cg_scal && blockIdx.x == 0 && threadIdx.x < 64) cg_scal[threadIdx.x] = 0.0;
   const int j = blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= P) return;
   const double* c = Cp + (size_t)j * 6;
@@ -902,18 +906,24 @@ __global__ __launch_bounds__(64 * SFM_SCHUR_WG_WAVES) __attribute__((amdgpu_wave
   SCHUR_STAMP_END(end - beg);
 }
 
-// grid (C, ceil(C/2)); 128 threads per block pair (c, c2): thread e < D*D owns element (e / D, e % D).
-template <int D>
-__global__ __launch_bounds__(256) void k_schur_assemble(int C, const int* __restrict__ item_ptr,
+// grid (C, ceil(C / ASM_NB)), 128 threads: workgroup (r, y) sums the item tiles of the blocks (r, c), c = ASM_NB y .. <= r, of the
+// LOWER triangle of S - thread e < D * D owns element (e / D, e % D) of every one of them - and writes its strip as whole rows of
+// up to ASM_NB D doubles through LDS.  ONLY THE LOWER TRIANGLE of S is ever read (k_diag_einv, k_scale_system, the multi-rank
+// exchange sfm_ba_pack_system, the factorisation: test_upper_triangle_of_S_is_never_read poisons the rest), so nothing else is
+// written; the items hold the UPPER blocks (c, r), c <= r, so element (rr, col) of block (r, c) is the transposed element of the
+// item tiles.  (The first form wrote each block by itself, and its mirror: 80-byte row segments, 0.42 ms at 1000 cameras.)
+constexpr int CGS_FAIL_WORD = 3;      // = CGS_FAIL (the camera CG's status words are declared with the CG, further down)
+// ASM_NB blocks per workgroup: 8 (640-byte rows) from 128 cameras on; 2 below - a thread sums its element of every block of the
+// workgroup in turn, and with few cameras a block holds many items (50 cameras / 200k observations: 4 per block) while the grid
+// is small: at cfg3 eight blocks per workgroup cost 11 us more than they saved
+template <int D, int ASM_NB>
+__global__ __launch_bounds__(128) void k_schur_assemble(int C, const int* __restrict__ item_ptr,
                                                         const double* __restrict__ part,
                                                         const double* __restrict__ B, double* __restrict__ S, double* __restrict__ cg_scal,
                                                         const int* __restrict__ cch_ptr, const double* __restrict__ cch_part,
-                                                        const double* __restrict__ gc, double* __restrict__ rhs_out) {
-  // the status words of the camera CG that follows start from zero (k_diag_einv only ever RAISES its failure word): cleared
-  // here, by the kernel that always runs before it, instead of by a memset between two kernels of the chain (a fill kernel of
-  // its own, ~5 us with its boundaries)
-  if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x < 64) cg_scal[threadIdx.x] = 0.0;
-  // ... and the right-hand side r_c = g_c - sum over the camera's chunk partials of sum_k G_k e_j (they came out of the
+                                                        const double* __restrict__ gc, double* __restrict__ rhs_out,
+                                                        double alpha, double* __restrict__ Einv /* null: no factors */, double* __restrict__ Efac) {
+  // the right-hand side r_c = g_c - sum over the camera's chunk partials of sum_k G_k e_j (they came out of the
   // diagonal-block items, or of the camera-wise pass): the first workgroup of a block row adds them up, four slots of chunks
   // side by side as k_cam_reduce_final does - that kernel was a launch of its own here (4.8 us plus a boundary)
   if (blockIdx.y == 0 && threadIdx.x < 64) {
@@ -923,27 +933,82 @@ __global__ __launch_bounds__(256) void k_schur_assemble(int C, const int* __rest
     const double t1 = __shfl(t, a + 16, 64), t2 = __shfl(t, a + 32, 64), t3 = __shfl(t, a + 48, 64);
     if (sl == 0 && a < D) rhs_out[cc * D + a] = gc[cc * D + a] - ((t + t1) + (t2 + t3));
   }
-  const int c = blockIdx.x;
-  const int c2 = c + blockIdx.y * 2 + (threadIdx.x >> 7);
-  const int e = threadIdx.x & 127;
-  if (c2 >= C || e >= D * D) return;
-  const int64_t blk = (int64_t)c * C - (int64_t)c * (c - 1) / 2 + (c2 - c);
-  const int rr = e / D, col = e - rr * D;
-  // the thread also sums the TRANSPOSED element (col, rr): it then writes the mirror block's entry (rr, col), so that both blocks
-  // leave as 80-byte row segments (from the element's own thread the mirror was 100 scattered 8-byte stores per block: worth
-  // 70 us of 420 at 1000 cameras, nothing measurable at 200)
-  // ONLY THE LOWER TRIANGLE of S is ever read (k_diag_einv, k_scale_system, the multi-rank exchange sfm_ba_pack_system, the
-  // factorisation: test_upper_triangle_of_S_is_never_read poisons the rest), so an off-diagonal block (c, c2 > c) leaves as its
-  // mirror (c2, c) alone - written from the transposed element, so that it too goes out as 80-byte row segments; the diagonal
-  // block is written whole.  (Writing both triangles was half of this kernel's 0.42 ms at 1000 cameras.)
-  const int eT = col * D + rr;
-  const int src = (c == c2) ? e : eT;
-  double s = 0.0;
-  for (int it = item_ptr[blk]; it < item_ptr[blk + 1]; ++it) s += part[(size_t)it * (D * D) + src];
-  double v = -s;
-  if (c == c2) v += B[(size_t)c * D * D + e];
-  const int n = C * D;
-  S[(size_t)(c2 * D + rr) * n + c * D + col] = v;
+  __shared__ double sOut[D][ASM_NB * D + 1];
+  const int r = blockIdx.x, c_0 = blockIdx.y * ASM_NB;
+  if (c_0 > r) return;                                   // (workgroup-uniform) right of the diagonal
+  const int nv = (r - c_0 + 1) < ASM_NB ? (r - c_0 + 1) : ASM_NB;
+  const int e = threadIdx.x;
+  if (e < D * D) {
+    const int rr = e / D, col = e - rr * D;
+    const int eT = col * D + rr;
+#pragma unroll
+    for (int j = 0; j < ASM_NB; ++j)
+      if (j < nv) {
+        const int c = c_0 + j;
+        const int64_t blk = (int64_t)c * C - (int64_t)c * (c - 1) / 2 + (r - c);
+        const int src = (c == r) ? e : eT;
+        double s = 0.0;
+        for (int it = item_ptr[blk]; it < item_ptr[blk + 1]; ++it) s += part[(size_t)it * (D * D) + src];
+        double v = -s;
+        if (c == r) v += B[(size_t)c * D * D + e];
+        sOut[rr][j * D + col] = v;
+      }
+  }
+  __syncthreads();
+  // The workgroup that holds the DIAGONAL block (r, r) also factors it for the camera CG: E_r = chol(S_rr + alpha I) and
+  // E_r^-1 - what k_diag_einv did as a launch of its own between this kernel and k_scale_system (11 us + a boundary per damped
+  // solve, one thread per camera with a 10 x 10 factorisation in 400 registers).  Here: the first D lanes of wave 0, lane i owning
+  // row i of L and, afterwards, column i of L^-1; what another lane holds comes by shuffle.  The same operations in the same order
+  // as small_chol_inverse: bit for bit the factors k_diag_einv produces.  Unsharded problems only - a rank's S is a partial sum
+  // until the exchange (sfm_ba_schur_solve runs k_diag_einv then).
+  if (Einv && r < c_0 + ASM_NB && e < D) {                // (c_0 <= r holds here)
+    const int jd = (r - c_0) * D, i = e;
+    double Lr[D], Xc[D];
+#pragma unroll
+    for (int k = 0; k < D; ++k) Lr[k] = (k <= i) ? sOut[i][jd + k] + (i == k ? alpha : 0.0) : 0.0;
+    bool ok = true;
+#pragma unroll
+    for (int j = 0; j < D; ++j) {
+      double sum = Lr[j];
+#pragma unroll
+      for (int k = 0; k < j; ++k) sum = fma(-Lr[k], Lr[k], sum);  // (lane j's value is the pivot's)
+      double piv = __shfl(sum, j, 64);
+      if (!(piv > 0.0)) { ok = false; piv = 1.0; }
+      const double l = sqrt(piv);
+      double t = Lr[j];
+#pragma unroll
+      for (int k = 0; k < j; ++k) t = fma(-Lr[k], __shfl(Lr[k], j, 64), t);
+      Lr[j] = (i == j) ? l : (i > j ? t / l : Lr[j]);
+    }
+    // column i of X = L^-1:  X[rw][i] = ([rw == i] - sum_{i <= k < rw} L[rw][k] X[k][i]) / L[rw][rw]
+#pragma unroll
+    for (int rw = 0; rw < D; ++rw) {
+      double sum = (rw == i) ? 1.0 : 0.0;
+#pragma unroll
+      for (int k = 0; k < rw; ++k) {
+        const double lrk = __shfl(Lr[k], rw, 64);
+        // (a fused multiply-add where k_diag_einv's unrolled `sum -= L[r][k] * X[k][t]` gets one: a product rounded on its own -
+        // what a select between product and zero compiles to - differs in the last bit)
+        sum = (k >= i) ? fma(-lrk, Xc[k], sum) : sum;
+      }
+      const double lrr = __shfl(Lr[rw], rw, 64);
+      Xc[rw] = (rw >= i) ? sum / lrr : 0.0;
+    }
+#pragma unroll
+    for (int k = 0; k < D; ++k) {
+      Efac[(size_t)r * D * D + i * D + k] = k <= i ? Lr[k] : 0.0;
+      Einv[(size_t)r * D * D + k * D + i] = Xc[k];
+    }
+    if (!ok) cg_scal[CGS_FAIL_WORD] = 1.0;
+  }
+  const int n = C * D, W = nv * D;
+  constexpr int WMAX = ASM_NB * D, NST = (D * WMAX + 127) / 128;
+#pragma unroll
+  for (int t = 0; t < NST; ++t) {
+    const int idx = e + 128 * t;
+    const int rr = idx / WMAX, col = idx - rr * WMAX;              // whole rows of the strip
+    if (rr < D && col < W) S[(size_t)(r * D + rr) * n + c_0 * D + col] = sOut[rr][col];
+  }
 }
 
 // out[c][a] = (base ? base[c][a] : 0) - sum_{k in camera c} sum_m G_k[m][a] vec[pt(k)][m]
@@ -1477,7 +1542,7 @@ extern "C" int sfm_ba_schur_build(sfm_handle h, sfm_ba_problem p, double alpha) 
   const int64_t N = p->n_obs;
   sfm_prof_begin(h, SFM_PROF_BUILD_G);
   hipLaunchKernelGGL(k_point_factor, dim3(cdiv(P, 256)), dim3(256), 0, h->stream, P, alpha, WS(L, Cp), WS(L, gp),
-                     WS(L, Linv), WS(L, e));
+                     WS(L, Linv), WS(L, e), WS(L, cg_scal));
   DISPATCH_DT(D, p->precision, {
     hipLaunchKernelGGL((k_build_G<DD, TT, double, GG>), dim3(cdiv(N, 256)), dim3(256), 0, h->stream, N, p->pt_idx, WST(L, recA),
                        WST(L, recB), WS(L, Linv), WS(L, G), WS(L, e), WS(L, eobs));
@@ -1502,10 +1567,19 @@ extern "C" int sfm_ba_schur_build(sfm_handle h, sfm_ba_problem p, double alpha) 
     if (p->has_dup && p->n_cchunks > 0)        // the chunk partials of sum_k G_k e_j by the camera-wise pass over G
       hipLaunchKernelGGL((k_cam_reduce_chunks<DD, double, GG>), dim3((unsigned)p->n_cchunks), dim3(256), 0, h->stream, p->cch_beg,
                          p->cch_end, p->cam_obs, p->pt_idx, WS(L, G), WS(L, e), WS(L, cch_part));
-    hipLaunchKernelGGL(k_schur_assemble<DD>, dim3(C, cdiv(C, 2)), dim3(256), 0, h->stream, C, p->item_ptr,
-                       WS(L, sch_part), WS(L, B), WS(L, red_S), WS(L, cg_scal), p->cch_ptr, WS(L, cch_part), WS(L, gc),
-                       WS(L, red_S) + (size_t)n * n);
+    // the diagonal blocks' factors for the camera CG come out of this kernel too (unsharded problems whose camera system may go to
+    // the CG: a rank's S is a partial sum until the exchange)
+    const bool fuse_einv = !p->sharded && p->camera_solver != SFM_CAMERA_SOLVER_CHOLESKY && (n & 1) == 0;
+    if (C >= 128)
+      hipLaunchKernelGGL((k_schur_assemble<DD, 8>), dim3(C, cdiv(C, 8)), dim3(128), 0, h->stream, C, p->item_ptr,
+                         WS(L, sch_part), WS(L, B), WS(L, red_S), WS(L, cg_scal), p->cch_ptr, WS(L, cch_part), WS(L, gc),
+                         WS(L, red_S) + (size_t)n * n, alpha, fuse_einv ? WS(L, cg_Minv) : (double*)nullptr, WS(L, cg_M));
+    else
+      hipLaunchKernelGGL((k_schur_assemble<DD, 2>), dim3(C, cdiv(C, 2)), dim3(128), 0, h->stream, C, p->item_ptr,
+                         WS(L, sch_part), WS(L, B), WS(L, red_S), WS(L, cg_scal), p->cch_ptr, WS(L, cch_part), WS(L, gc),
+                         WS(L, red_S) + (size_t)n * n, alpha, fuse_einv ? WS(L, cg_Minv) : (double*)nullptr, WS(L, cg_M));
     p->cg_scal_clean = 1;
+    p->einv_alpha = fuse_einv ? alpha : -1.0;
     sfm_prof_end(h, SFM_PROF_SCHUR);
   });
   SFM_LAUNCH_CHECK(h, "sfm_ba_schur_build");
@@ -1543,9 +1617,11 @@ __device__ __forceinline__ bool small_chol_inverse(double (&L)[D][D], double (&X
   bool ok = true;
 #pragma unroll
   for (int j = 0; j < D; ++j) {
+    // (explicit fused multiply-adds: the cooperative form of this routine in k_schur_assemble must round exactly alike, and what
+    // the compiler contracts on its own depends on the code around it)
     double sum = L[j][j];
 #pragma unroll
-    for (int k = 0; k < j; ++k) sum -= L[j][k] * L[j][k];
+    for (int k = 0; k < j; ++k) sum = fma(-L[j][k], L[j][k], sum);
     if (!(sum > 0.0)) { ok = false; sum = 1.0; }
     const double l = sqrt(sum);
     L[j][j] = l;
@@ -1553,7 +1629,7 @@ __device__ __forceinline__ bool small_chol_inverse(double (&L)[D][D], double (&X
     for (int i = j + 1; i < D; ++i) {
       double t = L[i][j];
 #pragma unroll
-      for (int k = 0; k < j; ++k) t -= L[i][k] * L[j][k];
+      for (int k = 0; k < j; ++k) t = fma(-L[i][k], L[j][k], t);
       L[i][j] = t / l;
     }
   }
@@ -1563,7 +1639,7 @@ __device__ __forceinline__ bool small_chol_inverse(double (&L)[D][D], double (&X
     for (int r = 0; r < D; ++r) {
       double sum = (r == t) ? 1.0 : 0.0;
 #pragma unroll
-      for (int k = 0; k < r; ++k) sum -= (k >= t ? L[r][k] * X[k][t] : 0.0);
+      for (int k = 0; k < r; ++k) sum = (k >= t) ? fma(-L[r][k], X[k][t], sum) : sum;
       X[r][t] = (r >= t) ? sum / L[r][r] : 0.0;
     }
   return ok;
@@ -1685,7 +1761,9 @@ __global__ __launch_bounds__(128) void k_scale_system(int n, int C, const double
 // plus, inside the diagonal tiles, the entries above the diagonal: blocks (c, c2) with c2 <= c and the band c < c2 <= c + BAND
 // (a 128-wide tile spans at most 128 / D + 2 cameras).  Every block is read from the lower triangle of S and written ONCE, in
 // its own rows (80-byte row segments): half the bytes of k_scale_system and none of its column-strided mirror writes
-// (0.53 -> 0.2x ms at 1000 cameras).
+// (0.53 -> 0.35 ms at 1000 cameras).  A form that moves whole 640-byte rows of the strip through LDS (every workgroup computing all
+// its blocks, the transposes bit-identical) was built and measured SLOWER: 35 against 21 us at 200 cameras, +0.1 ms at 1000 - the
+// kernel is bound by the latency of its few dependent stages per workgroup, not by the width of its accesses.
 template <int D>
 __global__ __launch_bounds__(128) void k_scale_system_lower(int n, int C, const double* __restrict__ S, double alpha,
                                                             const double* __restrict__ Einv, double* __restrict__ St,
@@ -2639,10 +2717,13 @@ extern "C" int sfm_ba_schur_solve(sfm_handle h, sfm_ba_problem p, double alpha, 
     // S~ = E^-1 (S + alpha I) E^-T into the factor's buffer (S stays as it is: the fallback below needs it), r~ = E^-1 r
     sfm_prof_begin(h, SFM_PROF_CHOL);
     // (cleared by k_schur_assemble when this solve follows its own sfm_ba_schur_build, as it does in every loop of this library)
-    if (!p->cg_scal_clean) SFM_HIP(h, hipMemsetAsync(WS(L, cg_scal), 0, 64 * sizeof(double), h->stream));
+    if (!p->cg_scal_clean) { SFM_HIP(h, hipMemsetAsync(WS(L, cg_scal), 0, 64 * sizeof(double), h->stream)); p->einv_alpha = -1.0; }
     p->cg_scal_clean = 0;
+    const bool have_einv = p->einv_alpha == alpha && !p->sharded;      // k_schur_assemble of THIS system left them
+    p->einv_alpha = -1.0;
     DISPATCH_D(D, {
-      hipLaunchKernelGGL(k_diag_einv<DD>, dim3(cdiv(C, 64)), dim3(64), 0, h->stream, C, S, n, alpha, WS(L, cg_Minv), WS(L, cg_M), WS(L, cg_scal));
+      if (!have_einv)
+        hipLaunchKernelGGL(k_diag_einv<DD>, dim3(cdiv(C, 64)), dim3(64), 0, h->stream, C, S, n, alpha, WS(L, cg_Minv), WS(L, cg_M), WS(L, cg_scal));
       if (cgs_use_big(n) && !cgs_persist_usable(h, n))   // the tile-streaming CG reads the lower triangle (+ the diagonal tiles) only
         hipLaunchKernelGGL(k_scale_system_lower<DD>, dim3(C, cdiv(C, SCALE_NB)), dim3(128), 0, h->stream, n, C, S, alpha, WS(L, cg_Minv), dw.Lm,
                            S + (size_t)n * n, WS(L, cg_r));

@@ -40,7 +40,8 @@ struct sfm_ba_prob {
                              // problems on one handle may both have a verdict in flight between finish_solve and read_scalars)
   int sharded;               // this problem is one rank's shard of a multi-rank solve (sfm_ba_set_sharded, or a reduce hook given to
                              // the loop / sfm_ba_solve_pcg): a route whose choice could differ between ranks is never switched locally
-  int cg_scal_clean;         // k_schur_assemble has just cleared the CG status words (sfm_ba_schur_solve then skips its memset)
+  int cg_scal_clean;         // sfm_ba_schur_build has just cleared the CG status words (sfm_ba_schur_solve then skips its memset)
+  double einv_alpha;         // >= 0: k_schur_assemble left the diagonal blocks' factors E_c, E_c^-1 for this alpha (unsharded problems)
   // 1: some camera appears more than once on a track.  The diagonal Schur blocks then hold cross pairs besides the
   // self-pairs, so k_schur_items must not take its fused diagonal path (one gather for both operands, right-hand side in
   // accumulator column D): every item runs the general path and the right-hand side comes from the camera-wise pass.
