@@ -154,6 +154,24 @@ __device__ __forceinline__ double wave_max(double v) {
   for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_down(v, o, 64));
   return v;
 }
+// v[q] = this lane's part of the sum of row q (8 rows); returns, in every lane, the sum over the 64 lanes of row
+// 4 (lane >> 5) + 2 ((lane >> 4) & 1) + ((lane >> 3) & 1): the halves of the wave, then neighbouring rows of 16 lanes, then the two
+// halves of a row of 16 each pass HALF of what they hold to their partner and keep the other half (4 + 2 + 1 additions), the
+// last eight lanes are summed by mirrors / quad permutes (3 additions).  Fixed order: the same bits on every workgroup.
+__device__ __forceinline__ double lane_rows8_sum(double (&v)[8], int lane) {
+  double u[4], x[2];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) u[k] = swap32_add(v[k], v[k + 4]);        // upper half keeps rows + 4
+#pragma unroll
+  for (int k = 0; k < 2; ++k) x[k] = swap16_add(u[k], u[k + 2]);        // odd rows of 16 lanes keep rows + 2
+  const bool hi = (lane & 8) != 0;                                      // lanes 8..15 of a row keep rows + 1
+  const double send = hi ? x[0] : x[1], keep = hi ? x[1] : x[0];
+  double t = keep + dpp_f64<0x140>(send);                               // row_mirror: lane i <-> lane 15 - i
+  t += dpp_f64<0x141>(t);                                               // row_half_mirror: lane i <-> lane 7 - i of its eight
+  t += dpp_f64<0xB1>(t);                                                // the four lanes of a quad
+  t += dpp_f64<0x4E>(t);
+  return t;
+}
 // Sum over a 256-thread block, fixed order, in every thread.  s: >= 4 doubles of LDS.
 __device__ __forceinline__ double block_sum256_fast(double v, double* s) {
   v = wave_sum_all(v);
@@ -1950,6 +1968,26 @@ __global__ __launch_bounds__(256) void k_cgs_iter(int n, int it, double rtol2, c
 // gives up posts the launch's salt in the abort word, which the others poll beside their granules, and the host then takes
 // the per-launch kernel (and stops using this one for the handle: a grid that is not co-resident - CUs taken by another
 // process - would pay the timeout on every solve otherwise).
+// Diagnostic build only (-DSFM_CGS_STAMPS=1, tools/exp_cgs_phases.sh): per-iteration phase stamps of workgroup 0 / thread 0 of
+// k_cgs_persist on the 100 MHz constant clock.  The shipped library executes no stamp.
+#ifndef SFM_CGS_STAMPS
+#define SFM_CGS_STAMPS 0
+#endif
+#if SFM_CGS_STAMPS
+constexpr int CGS_STAMP_SLOTS = 1 << 16;
+__device__ unsigned long long g_cgs_stamps[CGS_STAMP_SLOTS];
+__device__ unsigned int g_cgs_stamp_pos;
+extern "C" int sfm_debug_cgs_stamps(unsigned long long* dst, int n_words, unsigned int* n_used) {
+  if (hipMemcpyFromSymbol(n_used, HIP_SYMBOL(g_cgs_stamp_pos), 4, 0, hipMemcpyDeviceToHost) != hipSuccess) return 1;
+  return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_cgs_stamps), (size_t)n_words * 8, 0, hipMemcpyDeviceToHost);
+}
+// record (tag, time): tag 0 = launch start, 1 = rows in registers, 2 = product + wave sums done (publish), 3 = gather complete,
+// 4 = recurrences done (end of iteration), 5 = epilogue done
+#define CGS_STAMP(tag) do { if (stamp_on) { const unsigned q_ = atomicAdd(&g_cgs_stamp_pos, 2u); \
+    if (q_ + 1 < CGS_STAMP_SLOTS) { g_cgs_stamps[q_] = (tag); g_cgs_stamps[q_ + 1] = __builtin_amdgcn_s_memrealtime(); } } } while (0)
+#else
+#define CGS_STAMP(tag) do {} while (0)
+#endif
 constexpr int PR_ROWS = 8;
 constexpr int PR_MAX_N = 2048;                    // 8 rows x 2048 columns per workgroup in registers; grid = n / 8 <= 256
 constexpr unsigned PR_SPIN_LIMIT = 1u << 17;      // passes over a thread's granules (~1 us each) before giving up
@@ -2009,6 +2047,10 @@ __global__ __launch_bounds__(256, 1) void k_cgs_persist(int n, double rtol2, int
   // their spin bound, post the abort word and leave; the host then takes the launch-per-iteration route
   if (sabotage > 0 && blk == 1) return;
   const int row0 = blk * PR_ROWS;
+#if SFM_CGS_STAMPS
+  const bool stamp_on = blk == 0 && tid == 0;
+#endif
+  CGS_STAMP(0);
   // this thread's slice of the workgroup's rows: registers for the whole solve
   double2 sv[PR_ROWS][NC];
 #pragma unroll
@@ -2019,6 +2061,13 @@ __global__ __launch_bounds__(256, 1) void k_cgs_persist(int n, double rtol2, int
       sv[q][c] = (row < n && col < n) ? *(const double2*)(St + (size_t)row * n + col) : make_double2(0.0, 0.0);
     }
   double xv[2 * NC], rv[2 * NC], pv[2 * NC], bv[2 * NC];     // bv: the right-hand side itself (the q system's r~ . x~)
+#if SFM_CGS_STAMPS
+  { double keep_ = 0.0;
+#pragma unroll
+    for (int q = 0; q < PR_ROWS; ++q) keep_ += sv[q][0].x;
+    asm volatile("" :: "v"(keep_)); }      // (the stamp below must not be scheduled ahead of the row loads)
+#endif
+  CGS_STAMP(1);
 #pragma unroll
   for (int c = 0; c < NC; ++c) {
     const int col = 2 * tid + 512 * c;
@@ -2053,7 +2102,9 @@ __global__ __launch_bounds__(256, 1) void k_cgs_persist(int n, double rtol2, int
 
   // one round: y = S~ v for this workgroup's rows, published and gathered; returns false when the launch is abandoned
   double yv[2 * NC];
-  auto exchange = [&](const double (&v)[2 * NC], int round) -> bool {
+  // (dot: v . y over the whole vector, in every thread - its four wave parts travel through LDS together with the waves'
+  // verdicts on the gather, one barrier pair for both; meaningless when the round is abandoned)
+  auto exchange = [&](const double (&v)[2 * NC], int round, double& dot) -> bool {
     double acc[PR_ROWS];
 #pragma unroll
     for (int q = 0; q < PR_ROWS; ++q) {
@@ -2062,12 +2113,15 @@ __global__ __launch_bounds__(256, 1) void k_cgs_persist(int n, double rtol2, int
       for (int c = 0; c < NC; ++c) t += sv[q][c].x * v[2 * c] + sv[q][c].y * v[2 * c + 1];
       acc[q] = t;
     }
-#pragma unroll
-    for (int q = 0; q < PR_ROWS; ++q) {
-      const double t = wave_sum_all(acc[q]);
-      if (lane == 0) s_part[q][w] = t;
+    // the eight row sums over the wave by ONE halving exchange (lane_rows8_sum: 10 additions and 22 cross-lane moves) instead of
+    // eight full wave sums (48 and 96): in-kernel stamps put "product + wave sums" at 1.8 us of a 5.1-us iteration at n = 2,000
+    // (one wave per SIMD: every dependent step of the reduction is exposed)
+    {
+      const double t = lane_rows8_sum(acc, lane);
+      if ((lane & 7) == 0) s_part[((lane >> 5) << 2) | (((lane >> 4) & 1) << 1) | ((lane >> 3) & 1)][w] = t;
     }
     __syncthreads();
+    CGS_STAMP(2);
     const unsigned tag = salt * 256u + (unsigned)round + 1u;
     pr_u64* slot = mail + (size_t)(round & 1) * 2 * n;
     if (tid < PR_ROWS && row0 + tid < n) {
@@ -2081,6 +2135,13 @@ __global__ __launch_bounds__(256, 1) void k_cgs_persist(int n, double rtol2, int
       else asm volatile("global_store_dwordx4 %0, %1, off sc1" :: "v"(slot + 2 * (size_t)(row0 + tid)), "v"(pk) : "memory");
     }
     // gather this thread's columns: 4 granules per chunk (two doubles), re-read until every tag matches
+    // ... but not at once: nothing can have arrived before the slowest workgroup's store has crossed the fabric, and a pass that
+    // comes too early is not free - 250 workgroups x 32 KB of L1-bypassing loads compete with the very stores they wait for,
+    // and the lines they pull are invalidated again a moment later.  In-kernel stamps (tools/exp_cgs_phases.sh, n = 2,000):
+    // publish -> gather complete 2.83 us polling at once, 1.78 with s_sleep 8 (x 64 clocks) in front, 1.56-1.59 with 24, 1.91
+    // with 40, 2.57 with 64; n = 500 (63 workgroups, one chunk per thread): 0.98 at once, 1.08 with 8, 1.31 with 24.
+    constexpr int FIRST_SLEEP = NC == 1 ? 0 : 6 * NC - 4;          // 8 / 14 / 20 for two / three / four chunks per thread
+    if (FIRST_SLEEP > 0) __builtin_amdgcn_s_sleep(FIRST_SLEEP);
     bool ok = false;
     for (unsigned spins = 0; spins < PR_SPIN_LIMIT; ++spins) {
       pr_u64 g[4 * NC];
@@ -2122,10 +2183,17 @@ __global__ __launch_bounds__(256, 1) void k_cgs_persist(int n, double rtol2, int
       }
       __builtin_amdgcn_s_sleep(2);                    // (polling without the sleep measured the same: 135.1 / 100.1 us per system)
     }
-    if (lane == 0) s_ok[w] = ok ? 1 : 0;
+    CGS_STAMP(3);
+    double td = 0.0;
+#pragma unroll
+    for (int i = 0; i < 2 * NC; ++i) td += v[i] * yv[i];
+    td = wave_sum_all(td);
+    // (s_red / s_ok were last READ before the barrier above - the one behind the s_part writes - so they can be written here
+    // without another one in front; their next writer, the block sum of r . r, starts with a barrier of its own)
+    if (lane == 0) { s_red[w] = td; s_ok[w] = ok ? 1 : 0; }
     __syncthreads();
     const bool all_ok = (s_ok[0] & s_ok[1] & s_ok[2] & s_ok[3]) != 0;
-    __syncthreads();                                // s_part / s_ok are rewritten by the next round
+    dot = (s_red[0] + s_red[1]) + (s_red[2] + s_red[3]);
     if (!all_ok && tid == 0) __hip_atomic_store(abort_w, (pr_u64)salt, PR_RLX_AGENT);
     return all_ok;
   };
@@ -2200,7 +2268,8 @@ __global__ __launch_bounds__(256, 1) void k_cgs_persist(int n, double rtol2, int
 
   int round = 0;
   if (x0) {                                         // warm start: r = rhs - S~ x0 (one more round of the same exchange)
-    if (!exchange(xv, round++)) { finish(rr0, 0, -1.0, 0.0); return; }
+    double unused;
+    if (!exchange(xv, round++, unused)) { finish(rr0, 0, -1.0, 0.0); return; }
 #pragma unroll
     for (int i = 0; i < 2 * NC; ++i) rv[i] -= yv[i];
   }
@@ -2222,11 +2291,8 @@ __global__ __launch_bounds__(256, 1) void k_cgs_persist(int n, double rtol2, int
   int it = 0;
   for (; it < max_iter; ++it) {
     if (rr <= rtol2 * rr0) { finish(rr, it, 1.0, 0.0); return; }
-    if (!exchange(pv, round++)) { finish(rr, it, -1.0, 0.0); return; }
-    double t = 0.0;
-#pragma unroll
-    for (int i = 0; i < 2 * NC; ++i) t += pv[i] * yv[i];
-    const double pAp = block_sum256_fast(t, s_red);
+    double pAp;
+    if (!exchange(pv, round++, pAp)) { finish(rr, it, -1.0, 0.0); return; }
     if (!(pAp > 0.0)) { finish(rr, it, 1.0, 2.0); return; }       // non-positive curvature (or NaN): S~ is not positive definite
     const double a = rr / pAp;
     double t2 = 0.0;
@@ -2237,6 +2303,7 @@ __global__ __launch_bounds__(256, 1) void k_cgs_persist(int n, double rtol2, int
 #pragma unroll
     for (int i = 0; i < 2 * NC; ++i) pv[i] = rv[i] + beta * pv[i];
     rr = rr_new;
+    CGS_STAMP(4);
   }
   finish(rr, it, rr <= rtol2 * rr0 ? 1.0 : 0.0, 0.0);
 }
