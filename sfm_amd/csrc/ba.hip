@@ -538,14 +538,18 @@ __global__ __launch_bounds__(256) void k_lin_finalize(int n, int D, const double
                                                       double* __restrict__ red_lin, double* __restrict__ gmax) {
   __shared__ double s_red[4];
   const int tid = threadIdx.x;
+  #pragma unroll 8
   for (int i = tid; i < n; i += 256) {
     red_lin[i] = gc[i];
     const int cam = i / D, a = i - cam * D;
     red_lin[n + 2 + i] = B[(size_t)cam * D * D + a * D + a];
   }
   double c = 0.0, g2 = 0.0, gm = 0.0, cm = 0.0;
+  #pragma unroll 8
   for (int i = tid; i < nblk_obs; i += 256) c += part_obs[i];
+  #pragma unroll 8
   for (int i = tid; i < n_reg; i += 256) c += cost_reg[i];
+  #pragma unroll 8
   for (int i = tid; i < nblk_pt; i += 256) { g2 += part_pt[4 * i]; gm = fmax(gm, part_pt[4 * i + 1]); cm = fmax(cm, part_pt[4 * i + 2]); }
   double ct = block_sum256(c, s_red);
   double g2t = block_sum256(g2, s_red);
@@ -559,6 +563,7 @@ __global__ __launch_bounds__(256) void k_finish_linearize(int n, const double* _
                                                           double* __restrict__ sc, double* __restrict__ hsc) {
   __shared__ double s_red[4];
   double g2 = 0.0, gm = 0.0, hm = 0.0;
+  #pragma unroll 8
   for (int i = threadIdx.x; i < n; i += 256) {
     double v = red_lin[i]; g2 += v * v; gm = fmax(gm, fabs(v));
     hm = fmax(hm, red_lin[n + 2 + i]);
@@ -1330,20 +1335,27 @@ __global__ void k_reg_step(int C, const double* __restrict__ cams_new, const dou
   cost_reg[(size_t)c * 4 + 2] = gts;
 }
 
-// red_step = [ js2, gts, cost_new, s_pts2, xnew_pts2 ] (this rank's partial sums, fixed order)
+// red_step = [ js2, gts, cost_new, s_pts2, xnew_pts2 ] (this rank's partial sums, fixed order).
+// The single-workgroup sums of this kernel and of k_lin_finalize / k_finish_step / k_finish_linearize walk ~4,000 block partials,
+// 16 per thread: with a run-time trip count the loop waited for every load before issuing the next (12-14 us per kernel);
+// `#pragma unroll 8` lets eight loads be in flight while the additions keep their order (the same bits).
 __global__ __launch_bounds__(256) void k_step_finalize(const double* __restrict__ part_obs, int nblk_obs,
                                                        int nblk_rows, const double* __restrict__ part_x, int nblk_x,
                                                        const double* __restrict__ cost_reg, int n_reg,
                                                        int with_lin, double* __restrict__ red_step) {
   __shared__ double s_red[4];
   double v[5] = {0, 0, 0, 0, 0};
+  #pragma unroll 8
   for (int i = threadIdx.x; i < nblk_obs; i += 256) v[2] += part_obs[(size_t)i * 4 + 2];
   if (with_lin)
+    #pragma unroll 8
     for (int i = threadIdx.x; i < nblk_rows; i += 256) { v[0] += part_obs[(size_t)i * 4]; v[1] += part_obs[(size_t)i * 4 + 1]; }
+  #pragma unroll 8
   for (int i = threadIdx.x; i < n_reg; i += 256) {
     v[2] += cost_reg[(size_t)i * 4]; v[0] += cost_reg[(size_t)i * 4 + 1]; v[1] += cost_reg[(size_t)i * 4 + 2];
   }
   if (with_lin)
+    #pragma unroll 8
     for (int i = threadIdx.x; i < nblk_x; i += 256) { v[3] += part_x[(size_t)i * 2]; v[4] += part_x[(size_t)i * 2 + 1]; }
 #pragma unroll
   for (int q = 0; q < 5; ++q) {
@@ -1358,6 +1370,7 @@ __global__ __launch_bounds__(256) void k_finish_step(int n_c, const double* __re
                                                      double* __restrict__ sc, double* __restrict__ hsc) {
   __shared__ double s_red[4];
   double s2 = 0.0, x2 = 0.0;
+  #pragma unroll 8
   for (int i = threadIdx.x; i < n_c; i += 256) {
     const double s = scale * pc[i];
     s2 += s * s;
@@ -2140,7 +2153,11 @@ __global__ __launch_bounds__(256, 1) void k_cgs_persist(int n, double rtol2, int
     // and the lines they pull are invalidated again a moment later.  In-kernel stamps (tools/exp_cgs_phases.sh, n = 2,000):
     // publish -> gather complete 2.83 us polling at once, 1.78 with s_sleep 8 (x 64 clocks) in front, 1.56-1.59 with 24, 1.91
     // with 40, 2.57 with 64; n = 500 (63 workgroups, one chunk per thread): 0.98 at once, 1.08 with 8, 1.31 with 24.
+#ifdef SFM_CGS_FIRST_SLEEP
+    constexpr int FIRST_SLEEP = SFM_CGS_FIRST_SLEEP;               // (sweeps: tools/exp_cgs_phases.sh)
+#else
     constexpr int FIRST_SLEEP = NC == 1 ? 0 : 6 * NC - 4;          // 8 / 14 / 20 for two / three / four chunks per thread
+#endif
     if (FIRST_SLEEP > 0) __builtin_amdgcn_s_sleep(FIRST_SLEEP);
     bool ok = false;
     for (unsigned spins = 0; spins < PR_SPIN_LIMIT; ++spins) {
@@ -2181,7 +2198,11 @@ __global__ __launch_bounds__(256, 1) void k_cgs_persist(int n, double rtol2, int
         if (one_xcd && __hip_atomic_load(tickets + 8, PR_RLX_AGENT) == 8u * (unsigned)need &&
             __hip_atomic_load(tickets, PR_RLX_AGENT) < (unsigned)need) break;     // every ticket is drawn and XCD 0 holds too few
       }
+#ifdef SFM_CGS_LOOP_SLEEP
+      __builtin_amdgcn_s_sleep(SFM_CGS_LOOP_SLEEP);
+#else
       __builtin_amdgcn_s_sleep(2);                    // (polling without the sleep measured the same: 135.1 / 100.1 us per system)
+#endif
     }
     CGS_STAMP(3);
     double td = 0.0;
