@@ -408,10 +408,41 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(KS == 8 ? S
 // order (16 values per half-wave); TH = TN >> 1 and the parity bit are taken from it in registers.
 // Two widths: KS = 4 (dim 128: SIFT, 128-bit strings) and KS = 8 (256 unpacked bits: ORB, find_matches.py:144 - twice the
 // MFMAs per step for the same filter and ranking work, two query blocks per wave).
+// The same launch also does the two other things the distance kernel waits for - the query rows' norms (the workgroups past
+// the last tile: k_row_norm_u8's arithmetic with flip 0x7F) and "no bound yet" in the shared bounds u2 (every thread a few words)
+// - which were a launch and a fill of their own in front of every call: ~7 us of a 0.39-ms call at 50k x 50k.
 template <int KS>   // KS = dim / 32: 4 (SIFT) or 8 (256 unpacked bits)
 __global__ __launch_bounds__(64 * KS) void k_train_tile_u8(const uint8_t* __restrict__ x, int64_t n, uint8_t* __restrict__ xt,
-                                                           int* __restrict__ th_t, int* __restrict__ pb_t, int* __restrict__ fix_cnt) {
+                                                           int* __restrict__ th_t, int* __restrict__ pb_t, int* __restrict__ fix_cnt,
+                                                           int n_tile_blocks, const uint8_t* __restrict__ q, int64_t nq, int* __restrict__ qn,
+                                                           int* __restrict__ u2, int64_t n_u2) {
   constexpr int PPR = 2 * KS, DIM = 32 * KS;               // 16-byte pieces per row; a workgroup = 64 KS threads = the 32 rows of ONE tile
+  {
+    const int64_t total = (int64_t)gridDim.x * (64 * KS);
+    for (int64_t i = (int64_t)blockIdx.x * (64 * KS) + threadIdx.x; i < n_u2; i += total) u2[i] = 0x7F7F7F7F;
+  }
+  if ((int)blockIdx.x >= n_tile_blocks) {
+    // query norms: QN_j = sum (v + 1)^2 over the row, v = (byte ^ 0x7F) as int8; 2 KS lanes per row, adjacent and aligned
+    const int64_t t = (int64_t)(blockIdx.x - n_tile_blocks) * (64 * KS) + threadIdx.x;
+    const int64_t r = t / PPR;
+    const int part = (int)(t - r * PPR);
+    int s = 0;
+    if (r < nq) {
+      const uint4 v = *(const uint4*)(q + r * DIM + part * 16);
+      const uint32_t wds[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+      for (int qq = 0; qq < 4; ++qq)
+#pragma unroll
+        for (int sh = 0; sh < 32; sh += 8) {
+          const int b = (int)(int8_t)(((wds[qq] >> sh) & 0xFFu) ^ 0x7Fu) + 1;
+          s += b * b;
+        }
+    }
+#pragma unroll
+    for (int o = PPR >> 1; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    if (r < nq && part == 0) qn[r] = s;
+    return;
+  }
   __shared__ int s_pb[2];
   if (threadIdx.x < 2) s_pb[threadIdx.x] = 0;
   if (blockIdx.x == 0 && threadIdx.x == 0) *fix_cnt = 0;    // the re-rank list of this call starts empty (filled by k_merge_splits_u8)
@@ -1057,17 +1088,23 @@ static int match_launch(sfm_ctx* h, int metric, const void* q, int64_t nq_rows, 
     const bool direct = (qb4 || direct2) && !(d_env && d_env[0] == '0');
     if (direct)
       {
-      if (dim == 256) hipLaunchKernelGGL(k_train_tile_u8<8>, dim3((unsigned)((nt_rows + 31) >> 5)), dim3(512), 0, h->stream, t8, nt_rows, w.tf, w.th, w.par, w.fix_cnt);
-      else hipLaunchKernelGGL(k_train_tile_u8<4>, dim3((unsigned)((nt_rows + 31) >> 5)), dim3(256), 0, h->stream, t8, nt_rows, w.tf, w.th, w.par, w.fix_cnt);
+      // one pre-pass launch: train tiles, then the query norms, and the bounds' initial value on the side
+      const unsigned tb = (unsigned)((nt_rows + 31) >> 5);
+      const int64_t n_u2 = n_out + 128;
+      if (dim == 256) hipLaunchKernelGGL(k_train_tile_u8<8>, dim3(tb + cdiv(nq_rows * 16, 512)), dim3(512), 0, h->stream, t8, nt_rows, w.tf, w.th, w.par, w.fix_cnt,
+                                         (int)tb, q8, nq_rows, w.qn, w.u2, n_u2);
+      else hipLaunchKernelGGL(k_train_tile_u8<4>, dim3(tb + cdiv(nq_rows * 8, 256)), dim3(256), 0, h->stream, t8, nt_rows, w.tf, w.th, w.par, w.fix_cnt,
+                              (int)tb, q8, nq_rows, w.qn, w.u2, n_u2);
     }
-    else
+    else {
       hipLaunchKernelGGL(k_train_prep_u8, dim3(cdiv((nt_rows + 1) * (dim >> 4), 256)), dim3(256), 0, h->stream, t8, nt_rows, dim, w.tf, w.th, w.par, w.fix_cnt);
-    hipLaunchKernelGGL(k_row_norm_u8, dim3(cdiv(nq_rows * (dim >> 4), 256)), dim3(256), 0, h->stream, q8, nq_rows, dim, 0x7F, 0, w.qn);
+      hipLaunchKernelGGL(k_row_norm_u8, dim3(cdiv(nq_rows * (dim >> 4), 256)), dim3(256), 0, h->stream, q8, nq_rows, dim, 0x7F, 0, w.qn);
+    }
     // the candidate filter pays once the queries see a few thousand train rows (see k_knn2_u8); below that it is 10
     // operations per tile for nothing
     const char* f_env = getenv("SFM_MATCH_FILTER");        // test / tuning knob: "0" off, "1" on
     const bool filter = f_env ? f_env[0] == '1' : filter_rows >= 2048;
-    if (filter || direct) SFM_HIP(h, hipMemsetAsync(w.u2, 0x7F, (size_t)(n_out + 128) * sizeof(int), h->stream));      // "no bound yet"
+    if (filter && !direct) SFM_HIP(h, hipMemsetAsync(w.u2, 0x7F, (size_t)(n_out + 128) * sizeof(int), h->stream));      // "no bound yet" (the direct path's pre-pass writes it)
     sfm_prof_begin(h, SFM_PROF_KNN);
 #define KNN_LAUNCH(KS, QB, F) hipLaunchKernelGGL((k_knn2_u8<KS, QB, F>), dim3(grid), dim3(256), 0, h->stream, q8, nq_rows, w.tf, nt_rows, w.th, w.par, w.qn, nsplit, rps, wg, n_out, w.part, w.u2)
     if (direct) {
