@@ -1798,13 +1798,14 @@ __global__ __launch_bounds__(128) void k_scale_system(int n, int C, const double
 template <int D>
 __global__ __launch_bounds__(128) void k_scale_system_lower(int n, int C, const double* __restrict__ S, double alpha,
                                                             const double* __restrict__ Einv, double* __restrict__ St,
-                                                            const double* __restrict__ rhs, double* __restrict__ rhs_t) {
+                                                            const double* __restrict__ rhs, double* __restrict__ rhs_t, int rev) {
   constexpr int BAND = 128 / D + 2;
   __shared__ double sB[SCALE_NB][D * D], sT[SCALE_NB][D * D], sE2[SCALE_NB][D * D], sE1[D * D];
-  const int c = blockIdx.x, e = threadIdx.x;
+  const int c = (rev & 2) ? (int)(gridDim.x - 1u - blockIdx.x) : (int)blockIdx.x, e = threadIdx.x;
   const int a = e / D, b = e - a * D;
-  const int c2_0 = blockIdx.y * SCALE_NB;
-  if (rhs_t && blockIdx.y == 0 && e < D) {
+  const int by = (rev & 1) ? (int)(gridDim.y - 1u - blockIdx.y) : (int)blockIdx.y;
+  const int c2_0 = by * SCALE_NB;
+  if (rhs_t && by == 0 && e < D) {
     double t = 0.0;
 #pragma unroll
     for (int k = 0; k < D; ++k) t += Einv[(size_t)c * D * D + e * D + k] * rhs[c * D + k];
@@ -2551,7 +2552,7 @@ __global__ __launch_bounds__(256) void k_cgb_init(int n, int nbp, const double* 
 }
 __global__ __launch_bounds__(256) void k_cgb_symv(int n, int nb, int nbp, int it, double rtol2, const double* __restrict__ St,
                                                   double* __restrict__ vec, const double* __restrict__ wv, const double* __restrict__ dots,
-                                                  double* __restrict__ P, double* __restrict__ scal, double* __restrict__ x_out) {
+                                                  double* __restrict__ P, double* __restrict__ scal, double* __restrict__ x_out, int flip) {
   // CGS_DONE holds 1 + the index of the launch that saw the end (converged or broken).  Only an EARLIER launch's verdict stops
   // this one: the tiles of the deciding launch itself all reach the same verdict from the same numbers, and each still has its
   // range of x to copy out - a tile that started late must not take tile 0's freshly written flag for yesterday's
@@ -2560,7 +2561,7 @@ __global__ __launch_bounds__(256) void k_cgb_symv(int n, int nb, int nbp, int it
   __shared__ double s_col[4][SY_T];
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   // t -> (I, J), J <= I: I = floor((sqrt(8 t + 1) - 1) / 2), corrected for the rounding of the root
-  const int t = (int)blockIdx.x;
+  const int t = flip ? (int)(gridDim.x - 1u - blockIdx.x) : (int)blockIdx.x;
   int I = (int)((sqrt(8.0 * (double)t + 1.0) - 1.0) * 0.5);
   while ((I + 1) * (I + 2) / 2 <= t) ++I;
   while (I * (I + 1) / 2 > t) --I;
@@ -2702,11 +2703,17 @@ static int cgs_solve_big(sfm_ctx* h, int n, const double* St, const double* rhs_
   hipLaunchKernelGGL(k_cgb_init, dim3(cdiv(n > 2 * nbp ? n : 2 * nbp, 256)), dim3(256), 0, h->stream, n, nbp, rhs_t, vec, dots, scal);
   // launch `it` forms r_it (it >= 1: from the dot products launch it - 1 left) and multiplies; launch it = k + 1 is the one that
   // sees iterate k converged and copies it out, so a system of k iterations takes k + 2 launch pairs
+  // The triangle (405 MB at n = 10,000) is larger than the memory-side cache (256 MB): walked in the same direction every
+  // iteration, nothing of it is ever found there (a cyclic walk is LRU's worst case); walked back and forth, the tail of the
+  // previous pass is.  Odd launches therefore take the tiles in descending order: 1,361 -> 1,215 us per second system at cfg5
+  // (tools/exp_mall_order.sh; SFM_CGB_ZIGZAG=0 restores the one-way walk).  Which tile a workgroup takes changes nothing in the
+  // arithmetic: every tile's partial sums go to its own slot.
+  static const int zigzag = getenv("SFM_CGB_ZIGZAG") ? atoi(getenv("SFM_CGB_ZIGZAG")) : 1;
   int it = 0;
   int batch = its_hint > 0 ? (its_hint + 4 > 48 ? 48 : its_hint + 4) : 24;
   while (it < CGS_BIG_MAX_ITER + 2) {
     for (int b = 0; b < batch && it < CGS_BIG_MAX_ITER + 2; ++b, ++it) {
-      hipLaunchKernelGGL(k_cgb_symv, dim3(n_tiles), dim3(256), 0, h->stream, n, nb, nbp, it, rtol2, St, vec, wv, dots, P, scal, x_t);
+      hipLaunchKernelGGL(k_cgb_symv, dim3(n_tiles), dim3(256), 0, h->stream, n, nb, nbp, it, rtol2, St, vec, wv, dots, P, scal, x_t, zigzag == 1 ? (it & 1) : (zigzag == 2 ? ((it + 1) & 1) : 0));
       hipLaunchKernelGGL(k_cgb_reduce, dim3(nb), dim3(128), 0, h->stream, n, nb, nbp, it, P, vec, wv, dots, scal);
     }
     SFM_HIP(h, hipMemcpyAsync(h->pinned, scal, 8 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
@@ -2810,11 +2817,13 @@ extern "C" int sfm_ba_schur_solve(sfm_handle h, sfm_ba_problem p, double alpha, 
     const bool have_einv = p->einv_alpha == alpha && !p->sharded;      // k_schur_assemble of THIS system left them
     p->einv_alpha = -1.0;
     DISPATCH_D(D, {
+      // (descending strips and rows: what k_schur_assemble wrote last is read first - still in the memory-side cache at 1000 cameras)
+      static const int scale_rev = getenv("SFM_SCALE_REV") ? atoi(getenv("SFM_SCALE_REV")) : 3;
       if (!have_einv)
         hipLaunchKernelGGL(k_diag_einv<DD>, dim3(cdiv(C, 64)), dim3(64), 0, h->stream, C, S, n, alpha, WS(L, cg_Minv), WS(L, cg_M), WS(L, cg_scal));
       if (cgs_use_big(n) && !cgs_persist_usable(h, n))   // the tile-streaming CG reads the lower triangle (+ the diagonal tiles) only
         hipLaunchKernelGGL(k_scale_system_lower<DD>, dim3(C, cdiv(C, SCALE_NB)), dim3(128), 0, h->stream, n, C, S, alpha, WS(L, cg_Minv), dw.Lm,
-                           S + (size_t)n * n, WS(L, cg_r));
+                           S + (size_t)n * n, WS(L, cg_r), scale_rev);
       else
         hipLaunchKernelGGL(k_scale_system<DD>, dim3(C, cdiv(C, SCALE_NB)), dim3(128), 0, h->stream, n, C, S, alpha, WS(L, cg_Minv), dw.Lm,
                            S + (size_t)n * n, WS(L, cg_r));
