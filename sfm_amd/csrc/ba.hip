@@ -936,6 +936,83 @@ __global__ __launch_bounds__(64 * SFM_SCHUR_WG_WAVES) __attribute__((amdgpu_wave
 // written; the items hold the UPPER blocks (c, r), c <= r, so element (rr, col) of block (r, c) is the transposed element of the
 // item tiles.  (The first form wrote each block by itself, and its mirror: 80-byte row segments, 0.42 ms at 1000 cameras.)
 constexpr int CGS_FAIL_WORD = 3;      // = CGS_FAIL (the camera CG's status words are declared with the CG, further down)
+// E_r = chol(S_rr + alpha I) and E_r^-1 by the first D lanes of a wave: lane i owns row i of L and, afterwards, column i of L^-1;
+// what another lane holds comes by shuffle.  blk: the block's element (0, 0) in LDS (row stride ld; only its lower triangle is
+// read).  The same operations in the same order as small_chol_inverse: bit for bit the factors k_diag_einv produces.
+template <int D>
+__device__ __forceinline__ void diag_block_factor_lanes(const double* blk, int ld, double alpha, int i, int r,
+                                                        double* __restrict__ Einv, double* __restrict__ Efac, double* __restrict__ cg_scal) {
+  double Lr[D], Xc[D];
+#pragma unroll
+  for (int k = 0; k < D; ++k) Lr[k] = (k <= i) ? blk[i * ld + k] + (i == k ? alpha : 0.0) : 0.0;
+  bool ok = true;
+#pragma unroll
+  for (int j = 0; j < D; ++j) {
+    double sum = Lr[j];
+#pragma unroll
+    for (int k = 0; k < j; ++k) sum = fma(-Lr[k], Lr[k], sum);  // (lane j's value is the pivot's)
+    double piv = __shfl(sum, j, 64);
+    if (!(piv > 0.0)) { ok = false; piv = 1.0; }
+    const double l = sqrt(piv);
+    double t = Lr[j];
+#pragma unroll
+    for (int k = 0; k < j; ++k) t = fma(-Lr[k], __shfl(Lr[k], j, 64), t);
+    Lr[j] = (i == j) ? l : (i > j ? t / l : Lr[j]);
+  }
+  // column i of X = L^-1:  X[rw][i] = ([rw == i] - sum_{i <= k < rw} L[rw][k] X[k][i]) / L[rw][rw]
+#pragma unroll
+  for (int rw = 0; rw < D; ++rw) {
+    double sum = (rw == i) ? 1.0 : 0.0;
+#pragma unroll
+    for (int k = 0; k < rw; ++k) {
+      const double lrk = __shfl(Lr[k], rw, 64);
+      // (a fused multiply-add where k_diag_einv's unrolled `sum -= L[r][k] * X[k][t]` gets one: a product rounded on its own -
+      // what a select between product and zero compiles to - differs in the last bit)
+      sum = (k >= i) ? fma(-lrk, Xc[k], sum) : sum;
+    }
+    const double lrr = __shfl(Lr[rw], rw, 64);
+    Xc[rw] = (rw >= i) ? sum / lrr : 0.0;
+  }
+#pragma unroll
+  for (int k = 0; k < D; ++k) {
+    Efac[(size_t)r * D * D + i * D + k] = k <= i ? Lr[k] : 0.0;
+    Einv[(size_t)r * D * D + k * D + i] = Xc[k];
+  }
+  if (!ok) cg_scal[CGS_FAIL_WORD] = 1.0;
+}
+// v[j] = -(sum of the item tiles of block (r, c_0 + j)) (+ B_r on the diagonal block), j < nv, for element e of the block (the
+// transposed element of the tiles for c < r: the items hold the upper blocks).  The item ranges of all blocks are fetched first and
+// the tiles then walked ROUND BY ROUND - round i adds item i of every block that has one - so that up to ASM_NB loads are in
+// flight where a block-by-block walk waited for each block's chain (range, then tiles) in turn: 8 dependent round trips per
+// workgroup, which the launch covered with occupancy alone (198 us at 1000 cameras).  Every block's sum in the same order.
+template <int D, int ASM_NB>
+__device__ __forceinline__ void strip_item_sums(int C, int r, int c_0, int nv, int e, const int* __restrict__ item_ptr,
+                                                const double* __restrict__ part, const double* __restrict__ B, double (&v)[ASM_NB]) {
+  const int rr = e / D, col = e - rr * D;
+  const int eT = col * D + rr;
+  int ib[ASM_NB], ie[ASM_NB], mx = 0;
+#pragma unroll
+  for (int j = 0; j < ASM_NB; ++j) {
+    ib[j] = ie[j] = 0;
+    if (j < nv) {
+      const int c = c_0 + j;
+      const int64_t blk = (int64_t)c * C - (int64_t)c * (c - 1) / 2 + (r - c);
+      ib[j] = item_ptr[blk]; ie[j] = item_ptr[blk + 1];
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < ASM_NB; ++j) { v[j] = 0.0; mx = (ie[j] - ib[j]) > mx ? (ie[j] - ib[j]) : mx; }
+  for (int i = 0; i < mx; ++i) {
+#pragma unroll
+    for (int j = 0; j < ASM_NB; ++j)
+      if (ib[j] + i < ie[j]) v[j] += part[(size_t)(ib[j] + i) * (D * D) + ((c_0 + j == r) ? e : eT)];
+  }
+#pragma unroll
+  for (int j = 0; j < ASM_NB; ++j) {
+    v[j] = -v[j];
+    if (j < nv && c_0 + j == r) v[j] += B[(size_t)r * D * D + e];
+  }
+}
 // ASM_NB blocks per workgroup: 8 (640-byte rows) from 128 cameras on; 2 below - a thread sums its element of every block of the
 // workgroup in turn, and with few cameras a block holds many items (50 cameras / 200k observations: 4 per block) while the grid
 // is small: at cfg3 eight blocks per workgroup cost 11 us more than they saved
@@ -963,67 +1040,20 @@ __global__ __launch_bounds__(128) void k_schur_assemble(int C, const int* __rest
   const int e = threadIdx.x;
   if (e < D * D) {
     const int rr = e / D, col = e - rr * D;
-    const int eT = col * D + rr;
+    double v[ASM_NB];
+    strip_item_sums<D, ASM_NB>(C, r, c_0, nv, e, item_ptr, part, B, v);
 #pragma unroll
     for (int j = 0; j < ASM_NB; ++j)
-      if (j < nv) {
-        const int c = c_0 + j;
-        const int64_t blk = (int64_t)c * C - (int64_t)c * (c - 1) / 2 + (r - c);
-        const int src = (c == r) ? e : eT;
-        double s = 0.0;
-        for (int it = item_ptr[blk]; it < item_ptr[blk + 1]; ++it) s += part[(size_t)it * (D * D) + src];
-        double v = -s;
-        if (c == r) v += B[(size_t)c * D * D + e];
-        sOut[rr][j * D + col] = v;
-      }
+      if (j < nv) sOut[rr][j * D + col] = v[j];
   }
   __syncthreads();
   // The workgroup that holds the DIAGONAL block (r, r) also factors it for the camera CG: E_r = chol(S_rr + alpha I) and
   // E_r^-1 - what k_diag_einv did as a launch of its own between this kernel and k_scale_system (11 us + a boundary per damped
-  // solve, one thread per camera with a 10 x 10 factorisation in 400 registers).  Here: the first D lanes of wave 0, lane i owning
-  // row i of L and, afterwards, column i of L^-1; what another lane holds comes by shuffle.  The same operations in the same order
-  // as small_chol_inverse: bit for bit the factors k_diag_einv produces.  Unsharded problems only - a rank's S is a partial sum
-  // until the exchange (sfm_ba_schur_solve runs k_diag_einv then).
-  if (Einv && r < c_0 + ASM_NB && e < D) {                // (c_0 <= r holds here)
-    const int jd = (r - c_0) * D, i = e;
-    double Lr[D], Xc[D];
-#pragma unroll
-    for (int k = 0; k < D; ++k) Lr[k] = (k <= i) ? sOut[i][jd + k] + (i == k ? alpha : 0.0) : 0.0;
-    bool ok = true;
-#pragma unroll
-    for (int j = 0; j < D; ++j) {
-      double sum = Lr[j];
-#pragma unroll
-      for (int k = 0; k < j; ++k) sum = fma(-Lr[k], Lr[k], sum);  // (lane j's value is the pivot's)
-      double piv = __shfl(sum, j, 64);
-      if (!(piv > 0.0)) { ok = false; piv = 1.0; }
-      const double l = sqrt(piv);
-      double t = Lr[j];
-#pragma unroll
-      for (int k = 0; k < j; ++k) t = fma(-Lr[k], __shfl(Lr[k], j, 64), t);
-      Lr[j] = (i == j) ? l : (i > j ? t / l : Lr[j]);
-    }
-    // column i of X = L^-1:  X[rw][i] = ([rw == i] - sum_{i <= k < rw} L[rw][k] X[k][i]) / L[rw][rw]
-#pragma unroll
-    for (int rw = 0; rw < D; ++rw) {
-      double sum = (rw == i) ? 1.0 : 0.0;
-#pragma unroll
-      for (int k = 0; k < rw; ++k) {
-        const double lrk = __shfl(Lr[k], rw, 64);
-        // (a fused multiply-add where k_diag_einv's unrolled `sum -= L[r][k] * X[k][t]` gets one: a product rounded on its own -
-        // what a select between product and zero compiles to - differs in the last bit)
-        sum = (k >= i) ? fma(-lrk, Xc[k], sum) : sum;
-      }
-      const double lrr = __shfl(Lr[rw], rw, 64);
-      Xc[rw] = (rw >= i) ? sum / lrr : 0.0;
-    }
-#pragma unroll
-    for (int k = 0; k < D; ++k) {
-      Efac[(size_t)r * D * D + i * D + k] = k <= i ? Lr[k] : 0.0;
-      Einv[(size_t)r * D * D + k * D + i] = Xc[k];
-    }
-    if (!ok) cg_scal[CGS_FAIL_WORD] = 1.0;
-  }
+  // solve, one thread per camera with a 10 x 10 factorisation in 400 registers).  Here: the first D lanes of wave 0
+  // (diag_block_factor_lanes).  Unsharded problems only - a rank's S is a partial sum until the exchange (sfm_ba_schur_solve runs
+  // k_diag_einv then).
+  if (Einv && r < c_0 + ASM_NB && e < D)                  // (c_0 <= r holds here)
+    diag_block_factor_lanes<D>(&sOut[0][(r - c_0) * D], ASM_NB * D + 1, alpha, e, r, Einv, Efac, cg_scal);
   const int n = C * D, W = nv * D;
   constexpr int WMAX = ASM_NB * D, NST = (D * WMAX + 127) / 128;
 #pragma unroll
@@ -1031,6 +1061,141 @@ __global__ __launch_bounds__(128) void k_schur_assemble(int C, const int* __rest
     const int idx = e + 128 * t;
     const int rr = idx / WMAX, col = idx - rr * WMAX;              // whole rows of the strip
     if (rr < D && col < W) S[(size_t)(r * D + rr) * n + c_0 * D + col] = sOut[rr][col];
+  }
+}
+
+// ---- The tile-streaming route (n > 2,048, unsharded): S~ = E^-1 (S + alpha I) E^-T straight from the item tiles.
+// k_schur_assemble wrote S (400 MB at 1000 cameras) only for k_scale_system_lower to read it back and write S~ (another 400 MB,
+// 0.25-0.34 ms per damped solve): with the diagonal blocks' factors known BEFOREHAND (k_schur_diag: one small workgroup per
+// camera, the same sums in the same order as k_schur_assemble's, the same factor lanes) the assembling workgroup can scale its
+// strip in LDS and write S~ alone.  S itself is then not formed; the few consumers that need it (the factorisation a system falls
+// back to, sfm_ba_pack_system) run k_schur_assemble on the same item tiles first (schur_materialise_S).
+template <int D>
+__global__ __launch_bounds__(128) void k_schur_diag(int C, const int* __restrict__ item_ptr, const double* __restrict__ part,
+                                                    const double* __restrict__ B, double alpha, double* __restrict__ Einv,
+                                                    double* __restrict__ Efac, double* __restrict__ cg_scal) {
+  __shared__ double sBlk[D][D + 1];
+  const int r = blockIdx.x, e = threadIdx.x;
+  if (e < D * D) {
+    const int rr = e / D, col = e - rr * D;
+    const int64_t blk = (int64_t)r * C - (int64_t)r * (r - 1) / 2;
+    double s = 0.0;
+#pragma unroll 4
+    for (int it = item_ptr[blk]; it < item_ptr[blk + 1]; ++it) s += part[(size_t)it * (D * D) + e];      // (a diagonal block holds ~20 items at 1000 cameras)
+    double v = -s;
+    v += B[(size_t)r * D * D + e];
+    sBlk[rr][col] = v;
+  }
+  __syncthreads();
+  if (e < D) diag_block_factor_lanes<D>(&sBlk[0][0], D + 1, alpha, e, r, Einv, Efac, cg_scal);
+}
+// grid and strips as k_schur_assemble.  Writes, of S~: the strip's blocks (r, c), c <= r, as whole rows; the transposes (c, r) of
+// the blocks with r - c <= SCALED_BAND (the 128 x 128 diagonal tiles of the tile kernel reach above the diagonal: a tile spans at
+// most 128 / D + 2 cameras) - exact transposes, so the diagonal tiles are symmetric to the bit; r~ = E^-1 r (and r itself, which
+// the launch-per-iteration routes and the factorisation read).
+template <int D, int ASM_NB>
+__global__ __launch_bounds__(128) void k_schur_assemble_scaled(int C, const int* __restrict__ item_ptr, const double* __restrict__ part,
+                                                               const double* __restrict__ B, double* __restrict__ St,
+                                                               const int* __restrict__ cch_ptr, const double* __restrict__ cch_part,
+                                                               const double* __restrict__ gc, double* __restrict__ rhs_out,
+                                                               double* __restrict__ rhs_t, double alpha, const double* __restrict__ Einv) {
+  constexpr int SCALED_BAND = 128 / D + 2;
+  if (blockIdx.y == 0 && threadIdx.x < 64) {
+    const int cc = blockIdx.x, lane = threadIdx.x, sl = lane >> 4, a = lane & 15;
+    double t = 0.0;
+    for (int ch = cch_ptr[cc] + sl; ch < cch_ptr[cc + 1]; ch += 4) t += cch_part[(size_t)ch * 16 + a];
+    const double t1 = __shfl(t, a + 16, 64), t2 = __shfl(t, a + 32, 64), t3 = __shfl(t, a + 48, 64);
+    const double rv = (sl == 0 && a < D) ? gc[cc * D + a] - ((t + t1) + (t2 + t3)) : 0.0;
+    double ts = 0.0;
+#pragma unroll
+    for (int k = 0; k < D; ++k) ts += Einv[(size_t)cc * D * D + (a < D ? a : 0) * D + k] * __shfl(rv, k, 64);
+    if (sl == 0 && a < D) { rhs_out[cc * D + a] = rv; rhs_t[cc * D + a] = ts; }
+  }
+  __shared__ double sOut[D][ASM_NB * D + 1];
+  __shared__ double sE1[D * D], sE2[ASM_NB][D * D];
+  const int r = blockIdx.x, c_0 = blockIdx.y * ASM_NB;
+  if (c_0 > r) return;                                   // (workgroup-uniform) right of the diagonal
+  const int nv = (r - c_0 + 1) < ASM_NB ? (r - c_0 + 1) : ASM_NB;
+  const int e = threadIdx.x;
+  const int a = e / D, b = e - a * D;
+  if (e < D * D) {
+    double ev[ASM_NB + 1];
+    ev[ASM_NB] = Einv[(size_t)r * D * D + e];
+#pragma unroll
+    for (int j = 0; j < ASM_NB; ++j) ev[j] = j < nv ? Einv[(size_t)(c_0 + j) * D * D + e] : 0.0;
+    double v[ASM_NB];
+    strip_item_sums<D, ASM_NB>(C, r, c_0, nv, e, item_ptr, part, B, v);
+    sE1[e] = ev[ASM_NB];
+#pragma unroll
+    for (int j = 0; j < ASM_NB; ++j)
+      if (j < nv) { sOut[a][j * D + b] = v[j]; sE2[j][e] = ev[j]; }
+  }
+  __syncthreads();
+  // The two small products per block, T = E_r^-1 X and T E_c^-T, by ROW OWNERS: thread (j, h) forms row h of block j - its row of
+  // T stays in registers between the two products (one thread per output passes T through LDS and a barrier: k_scale_system_lower's
+  // form).  The terms of every sum in the same order as there.
+  // (the diagonal block first: its lower triangle mirrored - only that triangle of S is ever meant - and alpha on its diagonal)
+  const bool has_diag = r < c_0 + ASM_NB;                 // (workgroup-uniform)
+  const int jd = (r - c_0) * D;
+  double dv = 0.0;
+  if (has_diag && e < D * D) dv = (b <= a ? sOut[a][jd + b] : sOut[b][jd + a]) + (a == b ? alpha : 0.0);
+  __syncthreads();
+  if (has_diag && e < D * D) sOut[a][jd + b] = dv;
+  __syncthreads();
+  // (one row per thread: 300 us per launch at 1000 cameras; two rows per thread - half the LDS reads, twice the chain - 348)
+  constexpr int RPT = 1;                                  // rows per thread
+  constexpr int RH = D / RPT;
+  const int oj = e / RH, oh = e - oj * RH;                // block of the strip, first row
+  const bool owner = e < ASM_NB * RH && oj < nv;
+  double out[RPT][D];
+  if (owner) {
+#pragma unroll
+    for (int q = 0; q < RPT; ++q) {
+      const int ra = oh + q * RH;
+      double tr[D];
+#pragma unroll
+      for (int bb = 0; bb < D; ++bb) tr[bb] = 0.0;
+      // tr[bb] = sum_k E1[ra][k] X[k][bb], k ascending in every sum: one row of X per step
+#pragma unroll
+      for (int k = 0; k < D; ++k) {
+        const double e1 = sE1[ra * D + k];
+#pragma unroll
+        for (int bb = 0; bb < D; ++bb) tr[bb] = fma(e1, sOut[k][oj * D + bb], tr[bb]);
+        __builtin_amdgcn_sched_barrier(0);                // (left to itself the scheduler hoists all 200 LDS loads: 310 spilled registers)
+      }
+#pragma unroll
+      for (int bb = 0; bb < D; ++bb) {
+        double t = 0.0;
+#pragma unroll
+        for (int k = 0; k < D; ++k) t = fma(tr[k], sE2[oj][bb * D + k], t);
+        out[q][bb] = t;
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+  }
+  __syncthreads();                                        // every owner has read its block before any of it is overwritten
+  if (owner) {
+#pragma unroll
+    for (int q = 0; q < RPT; ++q)
+#pragma unroll
+      for (int bb = 0; bb < D; ++bb) sOut[oh + q * RH][oj * D + bb] = out[q][bb];
+  }
+  __syncthreads();
+  const int n = C * D, W = nv * D;
+  constexpr int WMAX = ASM_NB * D, NST = (D * WMAX + 127) / 128;
+#pragma unroll
+  for (int t = 0; t < NST; ++t) {
+    const int idx = e + 128 * t;
+    const int rr = idx / WMAX, col = idx - rr * WMAX;              // whole rows of the strip
+    if (rr < D && col < W) St[(size_t)(r * D + rr) * n + c_0 * D + col] = sOut[rr][col];
+  }
+  if (e < D * D) {
+#pragma unroll
+    for (int j = 0; j < ASM_NB; ++j) {
+      const int c = c_0 + j;
+      if (j < nv && c < r && r - c <= SCALED_BAND)                 // block (c, r) = the transpose: element (a, b) = S~_rc (b, a)
+        St[(size_t)(c * D + a) * n + r * D + b] = sOut[b][j * D + a];
+    }
   }
 }
 
@@ -1565,6 +1730,9 @@ extern "C" int sfm_ba_finish_linearize(sfm_handle h, sfm_ba_problem p) {
   return SFM_OK;
 }
 
+static bool cgs_use_big(int n);
+static bool cgs_persist_usable(sfm_ctx* h, int n);
+
 extern "C" int sfm_ba_schur_build(sfm_handle h, sfm_ba_problem p, double alpha) {
   Lay L; int rc = check_problem(h, p, &L); if (rc) return rc;
   if (!(alpha > 0.0)) return sfm_fail(h, SFM_ERR_ARG, "sfm_ba_schur_build", "alpha must be > 0");
@@ -1601,7 +1769,26 @@ extern "C" int sfm_ba_schur_build(sfm_handle h, sfm_ba_problem p, double alpha) 
     // the diagonal blocks' factors for the camera CG come out of this kernel too (unsharded problems whose camera system may go to
     // the CG: a rank's S is a partial sum until the exchange)
     const bool fuse_einv = !p->sharded && p->camera_solver != SFM_CAMERA_SOLVER_CHOLESKY && (n & 1) == 0;
-    if (C >= 128)
+    // ... and on the tile-streaming route the scaled system itself (S is then formed on demand only: schur_materialise_S)
+    const char* fse = getenv("SFM_SCHUR_FUSE_SCALE");      // "0": S first, then k_scale_system_lower (looked at per build: a test switches it)
+    const bool fuse_scale_on = !(fse && fse[0] == '0');
+    const bool fuse_scale = fuse_scale_on && fuse_einv && cgs_use_big(n) && !cgs_persist_usable(h, n);
+    p->st_alpha = -1.0;
+    p->s_valid = fuse_scale ? 0 : 1;
+    if (fuse_scale) {
+      DenseWs dw; dense_ws_carve(WS(L, dense), n, &dw);
+      hipLaunchKernelGGL(k_schur_diag<DD>, dim3(C), dim3(128), 0, h->stream, C, p->item_ptr, WS(L, sch_part), WS(L, B), alpha,
+                         WS(L, cg_Minv), WS(L, cg_M), WS(L, cg_scal));
+      if (C >= 128)
+        hipLaunchKernelGGL((k_schur_assemble_scaled<DD, 8>), dim3(C, cdiv(C, 8)), dim3(128), 0, h->stream, C, p->item_ptr,
+                           WS(L, sch_part), WS(L, B), dw.Lm, p->cch_ptr, WS(L, cch_part), WS(L, gc), WS(L, red_S) + (size_t)n * n,
+                           WS(L, cg_r), alpha, WS(L, cg_Minv));
+      else
+        hipLaunchKernelGGL((k_schur_assemble_scaled<DD, 2>), dim3(C, cdiv(C, 2)), dim3(128), 0, h->stream, C, p->item_ptr,
+                           WS(L, sch_part), WS(L, B), dw.Lm, p->cch_ptr, WS(L, cch_part), WS(L, gc), WS(L, red_S) + (size_t)n * n,
+                           WS(L, cg_r), alpha, WS(L, cg_Minv));
+      p->st_alpha = alpha;
+    } else if (C >= 128)
       hipLaunchKernelGGL((k_schur_assemble<DD, 8>), dim3(C, cdiv(C, 8)), dim3(128), 0, h->stream, C, p->item_ptr,
                          WS(L, sch_part), WS(L, B), WS(L, red_S), WS(L, cg_scal), p->cch_ptr, WS(L, cch_part), WS(L, gc),
                          WS(L, red_S) + (size_t)n * n, alpha, fuse_einv ? WS(L, cg_Minv) : (double*)nullptr, WS(L, cg_M));
@@ -1614,6 +1801,27 @@ extern "C" int sfm_ba_schur_build(sfm_handle h, sfm_ba_problem p, double alpha) 
     sfm_prof_end(h, SFM_PROF_SCHUR);
   });
   SFM_LAUNCH_CHECK(h, "sfm_ba_schur_build");
+  return SFM_OK;
+}
+
+// S (red_S) from the item tiles of the last sfm_ba_schur_build, for the consumers that need the unscaled system after a build
+// that formed S~ only: the factorisation (a system the CG is not given, or did not finish) and sfm_ba_pack_system.
+static int schur_materialise_S(sfm_ctx* h, sfm_ba_problem p, const Lay& L) {
+  if (p->s_valid) return SFM_OK;
+  double* ws = (double*)p->workspace;
+  const int C = p->n_cams, D = p->cam_dim, n = C * D;
+  DISPATCH_D(D, {
+    if (C >= 128)
+      hipLaunchKernelGGL((k_schur_assemble<DD, 8>), dim3(C, cdiv(C, 8)), dim3(128), 0, h->stream, C, p->item_ptr,
+                         WS(L, sch_part), WS(L, B), WS(L, red_S), WS(L, cg_scal), p->cch_ptr, WS(L, cch_part), WS(L, gc),
+                         WS(L, red_S) + (size_t)n * n, 0.0, (double*)nullptr, (double*)nullptr);
+    else
+      hipLaunchKernelGGL((k_schur_assemble<DD, 2>), dim3(C, cdiv(C, 2)), dim3(128), 0, h->stream, C, p->item_ptr,
+                         WS(L, sch_part), WS(L, B), WS(L, red_S), WS(L, cg_scal), p->cch_ptr, WS(L, cch_part), WS(L, gc),
+                         WS(L, red_S) + (size_t)n * n, 0.0, (double*)nullptr, (double*)nullptr);
+  });
+  p->s_valid = 1;
+  SFM_LAUNCH_CHECK(h, "schur_materialise_S");
   return SFM_OK;
 }
 
@@ -1634,6 +1842,8 @@ static int pack_S(sfm_handle h, sfm_ba_problem p, int unpack_dir, const char* wh
   double* ws = (double*)p->workspace;
   const int n = p->n_cams * p->cam_dim;
   DenseWs dw; dense_ws_carve(WS(L, dense), n, &dw);
+  if ((rc = schur_materialise_S(h, p, L))) return rc;
+  p->st_alpha = -1.0;                                  // the packed copy goes where S~ would be
   hipLaunchKernelGGL(k_pack_lower, dim3(n + 1), dim3(256), 0, h->stream, WS(L, red_S), n, dw.Lm, unpack_dir);
   SFM_LAUNCH_CHECK(h, what);
   return SFM_OK;
@@ -1699,6 +1909,8 @@ __global__ void k_finish_solve_pcg(int n, const double* __restrict__ pc, const d
 constexpr int CGS_MAX_N = 4096;          // the direction vector lives in LDS (32 KB); larger systems use the factorisation
 constexpr int CGS_MAX_ITER = 160;
 constexpr int CGS_BIG_MAX_ITER = 400;   // the tile-streaming route for n > CGS_MAX_N (cgs_solve_big)
+// (SFM_CGS_BIG_BUDGET: a TEST knob, looked at per solve - a budget of a few iterations makes a system fall back to the factorisation)
+static int cgs_big_budget() { const char* e = getenv("SFM_CGS_BIG_BUDGET"); const int v = e ? atoi(e) : 0; return v > 0 ? v : CGS_BIG_MAX_ITER; }
 // ||r|| <= CGS_RTOL ||r_0|| on the scaled system.  SFM_CGS_RTOL overrides it - a DIAGNOSTIC knob (tools/exp_cg_fixed_cost.py
 // sets 1.0: zero iterations, what remains is the fixed cost of a system), never set by the product
 static double cgs_rtol() { static const double v = getenv("SFM_CGS_RTOL") ? atof(getenv("SFM_CGS_RTOL")) : 1e-13; return v; }
@@ -2711,8 +2923,9 @@ static int cgs_solve_big(sfm_ctx* h, int n, const double* St, const double* rhs_
   static const int zigzag = getenv("SFM_CGB_ZIGZAG") ? atoi(getenv("SFM_CGB_ZIGZAG")) : 1;
   int it = 0;
   int batch = its_hint > 0 ? (its_hint + 4 > 48 ? 48 : its_hint + 4) : 24;
-  while (it < CGS_BIG_MAX_ITER + 2) {
-    for (int b = 0; b < batch && it < CGS_BIG_MAX_ITER + 2; ++b, ++it) {
+  const int budget = cgs_big_budget();
+  while (it < budget + 2) {
+    for (int b = 0; b < batch && it < budget + 2; ++b, ++it) {
       hipLaunchKernelGGL(k_cgb_symv, dim3(n_tiles), dim3(256), 0, h->stream, n, nb, nbp, it, rtol2, St, vec, wv, dots, P, scal, x_t, zigzag == 1 ? (it & 1) : (zigzag == 2 ? ((it + 1) & 1) : 0));
       hipLaunchKernelGGL(k_cgb_reduce, dim3(nb), dim3(128), 0, h->stream, n, nb, nbp, it, P, vec, wv, dots, scal);
     }
@@ -2783,7 +2996,7 @@ extern "C" int sfm_ba_schur_solve(sfm_handle h, sfm_ba_problem p, double alpha, 
   // depends on replicated quantities only (alpha, max diag H, iteration counts), so every rank of a sharded solve decides alike.
   const double hdiag = p->host_sc[SFM_SC_HDIAG];
   const double arel = hdiag > 0.0 ? alpha / hdiag : 0.0;
-  const int cg_budget = cgs_use_big(n) ? CGS_BIG_MAX_ITER : CGS_MAX_ITER;
+  const int cg_budget = cgs_use_big(n) ? cgs_big_budget() : CGS_MAX_ITER;
   bool hopeless = false;
   if (p->camera_solver == SFM_CAMERA_SOLVER_AUTO && arel > 0.0 && !(getenv("SFM_CGS_PREDICT") && getenv("SFM_CGS_PREDICT")[0] == '0')) {
     if (p->cgp_fail_rel > 0.0 && arel <= 4.0 * p->cgp_fail_rel) hopeless = true;
@@ -2816,7 +3029,10 @@ extern "C" int sfm_ba_schur_solve(sfm_handle h, sfm_ba_problem p, double alpha, 
     p->cg_scal_clean = 0;
     const bool have_einv = p->einv_alpha == alpha && !p->sharded;      // k_schur_assemble of THIS system left them
     p->einv_alpha = -1.0;
-    DISPATCH_D(D, {
+    // ... or the scaled system itself (tile-streaming route: k_schur_assemble_scaled)
+    const bool have_st = have_einv && p->st_alpha == alpha && cgs_use_big(n) && !cgs_persist_usable(h, n);
+    if (!have_st && (rc = schur_materialise_S(h, p, L))) return rc;
+    if (!have_st) DISPATCH_D(D, {
       // (descending strips and rows: what k_schur_assemble wrote last is read first - still in the memory-side cache at 1000 cameras)
       static const int scale_rev = getenv("SFM_SCALE_REV") ? atoi(getenv("SFM_SCALE_REV")) : 3;
       if (!have_einv)
@@ -2898,6 +3114,8 @@ extern "C" int sfm_ba_schur_solve(sfm_handle h, sfm_ba_problem p, double alpha, 
   }
   if (p->cg_state == 0) {
     sfm_prof_begin(h, SFM_PROF_CHOL);
+    if ((rc = schur_materialise_S(h, p, L))) return rc;
+    p->st_alpha = -1.0;                                // the factor goes where S~ was
     SFM_HIP(h, hipMemsetAsync(dw.flag, 0, sizeof(int), h->stream));       // the factorisation's failure flag (k_finish_solve reads it)
     hipLaunchKernelGGL(k_add_diag, dim3(cdiv(n, 256)), dim3(256), 0, h->stream, S, n, alpha);
     rc = dense_cholesky(h, S, n, n + 1, dw); if (rc) return rc;   // row n: r -> L^-1 r
@@ -2921,6 +3139,8 @@ static int finish_solve_by_factor(sfm_ctx* h, sfm_ba_problem p, const Lay& L, do
   if (factor_first) {
     p->cg_fallbacks++;
     p->cg_state = 0;
+    if ((rc = schur_materialise_S(h, p, L))) return rc;
+    p->st_alpha = -1.0;
     SFM_HIP(h, hipMemsetAsync(dw.flag, 0, sizeof(int), h->stream));
     hipLaunchKernelGGL(k_add_diag, dim3(cdiv(n, 256)), dim3(256), 0, h->stream, WS(L, red_S), n, p->cg_alpha);
     rc = dense_cholesky(h, WS(L, red_S), n, n + 1, dw); if (rc) return rc;

@@ -42,6 +42,8 @@ struct sfm_ba_prob {
                              // the loop / sfm_ba_solve_pcg): a route whose choice could differ between ranks is never switched locally
   int cg_scal_clean;         // sfm_ba_schur_build has just cleared the CG status words (sfm_ba_schur_solve then skips its memset)
   double einv_alpha;         // >= 0: k_schur_assemble left the diagonal blocks' factors E_c, E_c^-1 for this alpha (unsharded problems)
+  double st_alpha;           // > 0: sfm_ba_schur_build left the SCALED system S~ for this alpha in the factor's buffer (tile-streaming route)
+  int s_valid;               // S itself (red_S) holds the current system; 0: only S~ was formed - schur_materialise_S forms S from the items
   // 1: some camera appears more than once on a track.  The diagonal Schur blocks then hold cross pairs besides the
   // self-pairs, so k_schur_items must not take its fused diagonal path (one gather for both operands, right-hand side in
   // accumulator column D): every item runs the general path and the right-hand side comes from the camera-wise pass.

@@ -201,6 +201,7 @@ extern "C" int sfm_ba_create_problem(sfm_handle h, const sfm_ba_desc* d, sfm_ba_
   p->h = h;
   p->n_cams = C; p->n_pts = P; p->cam_dim = d->cam_dim; p->apply_reg = d->apply_reg; p->precision = d->precision;
   p->camera_solver = d->camera_solver;
+  p->einv_alpha = -1.0; p->st_alpha = -1.0; p->s_valid = 1;
   // pinned host mirror of the scalars (every kernel that writes one writes it here too: sfm_ba_read_scalars only waits)
   if (hipHostMalloc((void**)&p->host_sc, (SFM_SC_COUNT + 8) * sizeof(double), hipHostMallocDefault) != hipSuccess) {
     p->host_sc = nullptr; sfm_ba_destroy_problem(p);
