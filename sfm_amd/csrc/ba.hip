@@ -1013,10 +1013,11 @@ __device__ __forceinline__ void strip_item_sums(int C, int r, int c_0, int nv, i
     if (j < nv && c_0 + j == r) v[j] += B[(size_t)r * D * D + e];
   }
 }
+constexpr int ASM_ROUNDS_FROM = 512;   // cameras from which k_schur_assemble walks its item tiles round by round (strip_item_sums)
 // ASM_NB blocks per workgroup: 8 (640-byte rows) from 128 cameras on; 2 below - a thread sums its element of every block of the
 // workgroup in turn, and with few cameras a block holds many items (50 cameras / 200k observations: 4 per block) while the grid
 // is small: at cfg3 eight blocks per workgroup cost 11 us more than they saved
-template <int D, int ASM_NB>
+template <int D, int ASM_NB, bool ROUNDS>
 __global__ __launch_bounds__(128) void k_schur_assemble(int C, const int* __restrict__ item_ptr,
                                                         const double* __restrict__ part,
                                                         const double* __restrict__ B, double* __restrict__ S, double* __restrict__ cg_scal,
@@ -1040,11 +1041,27 @@ __global__ __launch_bounds__(128) void k_schur_assemble(int C, const int* __rest
   const int e = threadIdx.x;
   if (e < D * D) {
     const int rr = e / D, col = e - rr * D;
-    double v[ASM_NB];
-    strip_item_sums<D, ASM_NB>(C, r, c_0, nv, e, item_ptr, part, B, v);
+    if (ROUNDS) {
+      double v[ASM_NB];
+      strip_item_sums<D, ASM_NB>(C, r, c_0, nv, e, item_ptr, part, B, v);
 #pragma unroll
-    for (int j = 0; j < ASM_NB; ++j)
-      if (j < nv) sOut[rr][j * D + col] = v[j];
+      for (int j = 0; j < ASM_NB; ++j)
+        if (j < nv) sOut[rr][j * D + col] = v[j];
+    } else {                                             // block by block (few cameras: 22.1 us at 200 against 24.8 round by round)
+      const int eT = col * D + rr;
+#pragma unroll
+      for (int j = 0; j < ASM_NB; ++j)
+        if (j < nv) {
+          const int c = c_0 + j;
+          const int64_t blk = (int64_t)c * C - (int64_t)c * (c - 1) / 2 + (r - c);
+          const int src = (c == r) ? e : eT;
+          double s = 0.0;
+          for (int it = item_ptr[blk]; it < item_ptr[blk + 1]; ++it) s += part[(size_t)it * (D * D) + src];
+          double v = -s;
+          if (c == r) v += B[(size_t)c * D * D + e];
+          sOut[rr][j * D + col] = v;
+        }
+    }
   }
   __syncthreads();
   // The workgroup that holds the DIAGONAL block (r, r) also factors it for the camera CG: E_r = chol(S_rr + alpha I) and
@@ -1788,12 +1805,16 @@ extern "C" int sfm_ba_schur_build(sfm_handle h, sfm_ba_problem p, double alpha) 
                            WS(L, sch_part), WS(L, B), dw.Lm, p->cch_ptr, WS(L, cch_part), WS(L, gc), WS(L, red_S) + (size_t)n * n,
                            WS(L, cg_r), alpha, WS(L, cg_Minv));
       p->st_alpha = alpha;
-    } else if (C >= 128)
-      hipLaunchKernelGGL((k_schur_assemble<DD, 8>), dim3(C, cdiv(C, 8)), dim3(128), 0, h->stream, C, p->item_ptr,
+    } else if (C >= ASM_ROUNDS_FROM)
+      hipLaunchKernelGGL((k_schur_assemble<DD, 8, true>), dim3(C, cdiv(C, 8)), dim3(128), 0, h->stream, C, p->item_ptr,
+                         WS(L, sch_part), WS(L, B), WS(L, red_S), WS(L, cg_scal), p->cch_ptr, WS(L, cch_part), WS(L, gc),
+                         WS(L, red_S) + (size_t)n * n, alpha, fuse_einv ? WS(L, cg_Minv) : (double*)nullptr, WS(L, cg_M));
+    else if (C >= 128)
+      hipLaunchKernelGGL((k_schur_assemble<DD, 8, false>), dim3(C, cdiv(C, 8)), dim3(128), 0, h->stream, C, p->item_ptr,
                          WS(L, sch_part), WS(L, B), WS(L, red_S), WS(L, cg_scal), p->cch_ptr, WS(L, cch_part), WS(L, gc),
                          WS(L, red_S) + (size_t)n * n, alpha, fuse_einv ? WS(L, cg_Minv) : (double*)nullptr, WS(L, cg_M));
     else
-      hipLaunchKernelGGL((k_schur_assemble<DD, 2>), dim3(C, cdiv(C, 2)), dim3(128), 0, h->stream, C, p->item_ptr,
+      hipLaunchKernelGGL((k_schur_assemble<DD, 2, false>), dim3(C, cdiv(C, 2)), dim3(128), 0, h->stream, C, p->item_ptr,
                          WS(L, sch_part), WS(L, B), WS(L, red_S), WS(L, cg_scal), p->cch_ptr, WS(L, cch_part), WS(L, gc),
                          WS(L, red_S) + (size_t)n * n, alpha, fuse_einv ? WS(L, cg_Minv) : (double*)nullptr, WS(L, cg_M));
     p->cg_scal_clean = 1;
@@ -1811,12 +1832,16 @@ static int schur_materialise_S(sfm_ctx* h, sfm_ba_problem p, const Lay& L) {
   double* ws = (double*)p->workspace;
   const int C = p->n_cams, D = p->cam_dim, n = C * D;
   DISPATCH_D(D, {
-    if (C >= 128)
-      hipLaunchKernelGGL((k_schur_assemble<DD, 8>), dim3(C, cdiv(C, 8)), dim3(128), 0, h->stream, C, p->item_ptr,
+    if (C >= ASM_ROUNDS_FROM)
+      hipLaunchKernelGGL((k_schur_assemble<DD, 8, true>), dim3(C, cdiv(C, 8)), dim3(128), 0, h->stream, C, p->item_ptr,
+                         WS(L, sch_part), WS(L, B), WS(L, red_S), WS(L, cg_scal), p->cch_ptr, WS(L, cch_part), WS(L, gc),
+                         WS(L, red_S) + (size_t)n * n, 0.0, (double*)nullptr, (double*)nullptr);
+    else if (C >= 128)
+      hipLaunchKernelGGL((k_schur_assemble<DD, 8, false>), dim3(C, cdiv(C, 8)), dim3(128), 0, h->stream, C, p->item_ptr,
                          WS(L, sch_part), WS(L, B), WS(L, red_S), WS(L, cg_scal), p->cch_ptr, WS(L, cch_part), WS(L, gc),
                          WS(L, red_S) + (size_t)n * n, 0.0, (double*)nullptr, (double*)nullptr);
     else
-      hipLaunchKernelGGL((k_schur_assemble<DD, 2>), dim3(C, cdiv(C, 2)), dim3(128), 0, h->stream, C, p->item_ptr,
+      hipLaunchKernelGGL((k_schur_assemble<DD, 2, false>), dim3(C, cdiv(C, 2)), dim3(128), 0, h->stream, C, p->item_ptr,
                          WS(L, sch_part), WS(L, B), WS(L, red_S), WS(L, cg_scal), p->cch_ptr, WS(L, cch_part), WS(L, gc),
                          WS(L, red_S) + (size_t)n * n, 0.0, (double*)nullptr, (double*)nullptr);
   });
