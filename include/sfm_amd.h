@@ -295,7 +295,11 @@ int sfm_ba_solve_pcg(sfm_handle h, sfm_ba_problem p, double alpha, int want_q, d
 int sfm_ba_step(sfm_handle h, sfm_ba_problem p, const double* x, double scale, double* x_new);
 int sfm_ba_finish_step(sfm_handle h, sfm_ba_problem p, const double* x, double scale, const double* x_new);
 
-/* Copy the SFM_SC_COUNT scalars to the host (synchronises the stream).  This is also where a damped solve COMPLETES: the
+/* Copy the SFM_SC_COUNT scalars to the host.  Waits for the FINISHING call of the stage enqueued last (sfm_ba_finish_linearize /
+ * _finish_solve / _finish_step, sfm_ba_solve_pcg, the trust-region loop's own stages): its kernel publishes a ticket behind the
+ * scalars in a pinned page and this call spins on it, so it returns as soon as the scalars are there - everything enqueued BEFORE
+ * that kernel has completed by then (stream order), but the call is not a full stream synchronisation: work enqueued after a
+ * finishing call is not waited for (SFM_POLL_SCALARS=0 restores the synchronisation).  This is also where a damped solve COMPLETES: the
  * persistent conjugate-gradient launch of the second camera system (sfm_ba_finish_solve with want_q) is not waited for
  * there - its verdict arrives with this synchronisation, and if it did not converge the q term is redone from the
  * factorisation here (no exchange between ranks is involved).  Read the scalars through this call, not from the workspace. */

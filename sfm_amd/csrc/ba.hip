@@ -27,6 +27,14 @@
 
 typedef double v4d __attribute__((ext_vector_type(4)));
 
+// the ticket of a finished stage into the pinned page, BEHIND the scalars (sfm_ba_read_scalars spins on it); seq 0: none
+__device__ __forceinline__ void publish_ticket(double* hsc, double seq) {
+  if (seq > 0.0) {
+    __threadfence_system();
+    *(volatile double*)(hsc + SFM_HSC_SEQ) = seq;
+  }
+}
+
 #define EPS_D 2.220446049250313e-16
 #define SQRT_EPS_D 1.4901161193847656e-08
 #define CAMPRE 16   // r[3] t[3] fx fy cx cy  a b a1 b1 (Rodrigues coefficients)  |r|^2 pad
@@ -560,7 +568,7 @@ __global__ __launch_bounds__(256) void k_lin_finalize(int n, int D, const double
 
 __global__ __launch_bounds__(256) void k_finish_linearize(int n, const double* __restrict__ red_lin,
                                                           const double* __restrict__ gmax,
-                                                          double* __restrict__ sc, double* __restrict__ hsc) {
+                                                          double* __restrict__ sc, double* __restrict__ hsc, double seq) {
   __shared__ double s_red[4];
   double g2 = 0.0, gm = 0.0, hm = 0.0;
   #pragma unroll 8
@@ -576,6 +584,7 @@ __global__ __launch_bounds__(256) void k_finish_linearize(int n, const double* _
     sc[SFM_SC_GNORM2] = hsc[SFM_SC_GNORM2] = g2t + red_lin[n + 1];
     sc[SFM_SC_GINF] = hsc[SFM_SC_GINF] = fmax(gmt, gmax[0]);
     sc[SFM_SC_HDIAG] = hsc[SFM_SC_HDIAG] = fmax(hmt, gmax[1]);
+    publish_ticket(hsc, seq);
   }
 }
 
@@ -1392,7 +1401,8 @@ __global__ void k_add_vec(const double* __restrict__ a, const double* __restrict
 __global__ __launch_bounds__(256) void k_finish_solve(int n, const double* __restrict__ pc,
                                                       const double* __restrict__ red_q,
                                                       const double* __restrict__ y, int want_q,
-                                                      const int* __restrict__ flag, double* __restrict__ sc, double* __restrict__ hsc) {
+                                                      const int* __restrict__ flag, double* __restrict__ sc, double* __restrict__ hsc,
+                                                      double seq) {
   __shared__ double s_red[4];
   double a = 0.0, b = 0.0;
   for (int i = threadIdx.x; i < n; i += 256) {
@@ -1409,6 +1419,7 @@ __global__ __launch_bounds__(256) void k_finish_solve(int n, const double* __res
     int f = *flag;
     if (f == 0 && !(isfinite(pn2) && isfinite(pq))) f = 3;
     sc[SFM_SC_CHOL_FAIL] = hsc[SFM_SC_CHOL_FAIL] = (double)f;
+    publish_ticket(hsc, seq);
   }
 }
 
@@ -1549,7 +1560,7 @@ __global__ __launch_bounds__(256) void k_step_finalize(const double* __restrict_
 __global__ __launch_bounds__(256) void k_finish_step(int n_c, const double* __restrict__ pc, double scale,
                                                      const double* __restrict__ x_new,
                                                      const double* __restrict__ red_step,
-                                                     double* __restrict__ sc, double* __restrict__ hsc) {
+                                                     double* __restrict__ sc, double* __restrict__ hsc, double seq) {
   __shared__ double s_red[4];
   double s2 = 0.0, x2 = 0.0;
   #pragma unroll 8
@@ -1564,6 +1575,7 @@ __global__ __launch_bounds__(256) void k_finish_step(int n_c, const double* __re
     sc[SFM_SC_JS2] = hsc[SFM_SC_JS2] = red_step[0]; sc[SFM_SC_GTS] = hsc[SFM_SC_GTS] = red_step[1];
     sc[SFM_SC_COST_NEW] = hsc[SFM_SC_COST_NEW] = red_step[2];
     sc[SFM_SC_SNORM2] = hsc[SFM_SC_SNORM2] = a + red_step[3]; sc[SFM_SC_XNEW_NORM2] = hsc[SFM_SC_XNEW_NORM2] = b + red_step[4];
+    publish_ticket(hsc, seq);
   }
 }
 
@@ -1742,7 +1754,7 @@ extern "C" int sfm_ba_finish_linearize(sfm_handle h, sfm_ba_problem p) {
   Lay L; int rc = check_problem(h, p, &L); if (rc) return rc;
   double* ws = (double*)p->workspace;
   hipLaunchKernelGGL(k_finish_linearize, dim3(1), dim3(256), 0, h->stream, p->n_cams * p->cam_dim,
-                     WS(L, red_lin), WS(L, gmax), WS(L, scalars), p->host_sc);
+                     WS(L, red_lin), WS(L, gmax), WS(L, scalars), p->host_sc, next_ticket(p));
   SFM_LAUNCH_CHECK(h, "sfm_ba_finish_linearize");
   return SFM_OK;
 }
@@ -1915,7 +1927,7 @@ __device__ __forceinline__ bool small_chol_inverse(double (&L)[D][D], double (&X
 __global__ void k_dot(int n, const double* __restrict__ a, const double* __restrict__ b, double* __restrict__ out);
 __global__ void k_finish_solve_pcg(int n, const double* __restrict__ pc, const double* __restrict__ red_q, int want_q,
                                    const double* __restrict__ dotp, const double* __restrict__ failp, double* __restrict__ sc,
-                                   double* __restrict__ hsc);
+                                   double* __restrict__ hsc, double seq);
 
 // ------------------------------------------------------------------------------------ CG on the explicit reduced system
 // Once S has been formed (and, multi-rank, all-reduced) the replicated camera solve is a latency chain in the dense
@@ -2257,6 +2269,7 @@ struct PrFuse {
   int rhs_scaled;          // 1: `rhs` is rhs~ already (k_scale_system / k_block_mv formed it; Einv then only serves the epilogue).  Forming
                            //    it in the prologue - every workgroup all n entries, ~200 eight-byte loads per thread - took 17-19 us per
                            //    launch by in-kernel stamps, more than seven iterations
+  double fin_seq;          // (q system) the ticket sfm_ba_read_scalars waits for - published whatever the verdict: the host then looks at it
 };
 
 template <int NC, int D>
@@ -2476,6 +2489,7 @@ __global__ __launch_bounds__(256, 1) void k_cgs_persist(int n, double rtol2, int
       host_status[CGS_FAIL] = fail_now; host_status[CGS_DONE] = done;
     }
     const bool converged = done == 1.0 && fail == 0.0 && rr <= rtol2 * rr0;
+    if (!converged && f.fin_sc && tid == 0) publish_ticket(f.fin_hsc, f.fin_seq);      // (no scalars: the verdict is what the host finds)
     if (!converged || !(f.pc_out || f.fin_sc)) return;          // (workgroup-uniform)
     if (f.pc_out) {
       // p_c = -E^-T x~: entry (cam, a) needs the whole x~ block of its camera -> through LDS
@@ -2521,6 +2535,7 @@ __global__ __launch_bounds__(256, 1) void k_cgs_persist(int n, double rtol2, int
         double fl = scal[CGS_FAIL] != 0.0 ? 1.0 : 0.0;
         if (fl == 0.0 && !(isfinite(pn2) && isfinite(pq))) fl = 3.0;
         f.fin_sc[SFM_SC_CHOL_FAIL] = f.fin_hsc[SFM_SC_CHOL_FAIL] = fl;
+        publish_ticket(f.fin_hsc, f.fin_seq);
       }
     }
   };
@@ -3097,7 +3112,7 @@ extern "C" int sfm_ba_schur_solve(sfm_handle h, sfm_ba_problem p, double alpha, 
       // (converged / fall back) but must not idle the GPU for it: the status words are copied to pinned memory, an event is
       // recorded behind the copy, the back-substitution is enqueued on the assumption that the solve converged (it does: 0
       // fallbacks in the bench schedules), and only then the host waits - for the event, not for the stream.
-      PrFuse fuse = {WS(L, cg_Minv), nullptr, WS(L, pc), nullptr, nullptr, nullptr, nullptr, 1};      // rhs~ = cg_r (k_scale_system)
+      PrFuse fuse = {WS(L, cg_Minv), nullptr, WS(L, pc), nullptr, nullptr, nullptr, nullptr, 1, 0.0};      // rhs~ = cg_r (k_scale_system)
       const PrLaunch pl = {n, D, dw.Lm, WS(L, cg_r), x0, WS(L, cg_z), WS(L, cg_mail), WS(L, cg_scal), CGS_RTOL, fuse, h->pinned + SFM_PIN_CG1, 0};
       rc = cgs_persist_launch(h, pl);
       if (rc) return rc;
@@ -3185,7 +3200,7 @@ static int finish_solve_by_factor(sfm_ctx* h, sfm_ba_problem p, const Lay& L, do
     sfm_prof_end(h, SFM_PROF_TRSV);
   }
   hipLaunchKernelGGL(k_finish_solve, dim3(1), dim3(256), 0, h->stream, n, WS(L, pc), WS(L, red_q), WS(L, y),
-                     want_q, (const int*)dw.flag, WS(L, scalars), p->host_sc);
+                     want_q, (const int*)dw.flag, WS(L, scalars), p->host_sc, next_ticket(p));
   SFM_LAUNCH_CHECK(h, "sfm_ba_finish_solve");
   return SFM_OK;
 }
@@ -3212,8 +3227,8 @@ extern "C" int sfm_ba_finish_solve(sfm_handle h, sfm_ba_problem p, int want_q) {
         // rhs~2 = E^-1 (p_c + rhs2 pieces) by one small launch (in the CG kernel's prologue every workgroup formed all of it)
         DISPATCH_D(D, hipLaunchKernelGGL(k_block_mv<DD>, dim3(cdiv(n, 256)), dim3(256), 0, h->stream, C, WS(L, cg_Minv), WS(L, pc),
                                          WS(L, cg_r), 0, 1.0, WS(L, red_q)));
-        PrFuse fuse = {WS(L, cg_Minv), nullptr, nullptr, WS(L, pc), WS(L, red_q), WS(L, scalars), p->host_sc, 1};
-        const PrLaunch pl = {n, D, dw.Lm, WS(L, cg_r), nullptr, WS(L, cg_z), WS(L, cg_mail), WS(L, cg_scal), CGS_RTOL, fuse, p->host_sc + SFM_SC_COUNT, 1};
+        PrFuse fuse = {WS(L, cg_Minv), nullptr, nullptr, WS(L, pc), WS(L, red_q), WS(L, scalars), p->host_sc, 1, next_ticket(p)};
+        const PrLaunch pl = {n, D, dw.Lm, WS(L, cg_r), nullptr, WS(L, cg_z), WS(L, cg_mail), WS(L, cg_scal), CGS_RTOL, fuse, p->host_sc + SFM_HSC_CG2, 1};
         rc = cgs_persist_launch(h, pl);
         if (rc) return rc;
         if (!warm_on) {
@@ -3251,7 +3266,7 @@ extern "C" int sfm_ba_finish_solve(sfm_handle h, sfm_ba_problem p, int want_q) {
     }
     if (status == 0) {
       hipLaunchKernelGGL(k_finish_solve_pcg, dim3(1), dim3(256), 0, h->stream, n, WS(L, pc), WS(L, red_q), want_q, WS(L, cg_scal) + 8,
-                         WS(L, cg_scal) + CGS_FAIL, WS(L, scalars), p->host_sc);
+                         WS(L, cg_scal) + CGS_FAIL, WS(L, scalars), p->host_sc, next_ticket(p));
       SFM_LAUNCH_CHECK(h, "sfm_ba_finish_solve");
       return SFM_OK;
     }
@@ -3423,7 +3438,7 @@ __global__ __launch_bounds__(1024) void k_dot(int n, const double* __restrict__ 
 // scalars after a PCG solve: PNORM2 = ||p_c||^2 + sum ||p_p||^2, PQ = rhs2^T S^-1 rhs2 + sum ||v||^2, failure code
 __global__ __launch_bounds__(256) void k_finish_solve_pcg(int n, const double* __restrict__ pc, const double* __restrict__ red_q,
                                                           int want_q, const double* __restrict__ dotp, const double* __restrict__ failp,
-                                                          double* __restrict__ sc, double* __restrict__ hsc) {
+                                                          double* __restrict__ sc, double* __restrict__ hsc, double seq) {
   __shared__ double s_red[4];
   double a = 0.0;
   for (int i = threadIdx.x; i < n; i += 256) a += pc[i] * pc[i];
@@ -3434,6 +3449,7 @@ __global__ __launch_bounds__(256) void k_finish_solve_pcg(int n, const double* _
     double f = *failp != 0.0 ? 1.0 : 0.0;                   // 1: a block or S itself is not positive definite
     if (f == 0.0 && !(isfinite(pn2) && isfinite(pq))) f = 3.0;
     sc[SFM_SC_CHOL_FAIL] = hsc[SFM_SC_CHOL_FAIL] = f;
+    publish_ticket(hsc, seq);
   }
 }
 
@@ -3600,7 +3616,7 @@ extern "C" int sfm_ba_solve_pcg(sfm_handle h, sfm_ba_problem p, double alpha, in
     sfm_prof_end(h, SFM_PROF_TRSV);
   }
   hipLaunchKernelGGL(k_finish_solve_pcg, dim3(1), dim3(256), 0, h->stream, n, WS(L, pc), WS(L, red_q), want_q, WS(L, cg_scal) + CG_DOT,
-                     WS(L, cg_scal) + CG_FAIL, WS(L, scalars), p->host_sc);
+                     WS(L, cg_scal) + CG_FAIL, WS(L, scalars), p->host_sc, next_ticket(p));
   SFM_LAUNCH_CHECK(h, "sfm_ba_solve_pcg");
   if (iters_host) *iters_host = cg.iters;
   return SFM_OK;
@@ -3633,7 +3649,7 @@ extern "C" int sfm_ba_finish_step(sfm_handle h, sfm_ba_problem p, const double* 
   double* ws = (double*)p->workspace;
   (void)x;
   hipLaunchKernelGGL(k_finish_step, dim3(1), dim3(256), 0, h->stream, p->n_cams * p->cam_dim, WS(L, pc), scale,
-                     x_new, WS(L, red_step), WS(L, scalars), p->host_sc);
+                     x_new, WS(L, red_step), WS(L, scalars), p->host_sc, next_ticket(p));
   SFM_LAUNCH_CHECK(h, "sfm_ba_finish_step");
   return SFM_OK;
 }
@@ -3647,12 +3663,12 @@ __global__ __launch_bounds__(256) void k_sq_partials(int64_t n, const double* __
   if (threadIdx.x == 0) part[blockIdx.x] = a;
 }
 __global__ __launch_bounds__(256) void k_xnorm_finish(int n_c, const double* __restrict__ x, const double* __restrict__ red_step,
-                                                      double* __restrict__ sc, double* __restrict__ hsc) {
+                                                      double* __restrict__ sc, double* __restrict__ hsc, double seq) {
   __shared__ double s_red[4];
   double a = 0.0;
   for (int i = threadIdx.x; i < n_c; i += 256) a += x[i] * x[i];
   const double t = block_sum256(a, s_red);
-  if (threadIdx.x == 0) sc[SFM_SC_XNEW_NORM2] = hsc[SFM_SC_XNEW_NORM2] = t + red_step[4];
+  if (threadIdx.x == 0) { sc[SFM_SC_XNEW_NORM2] = hsc[SFM_SC_XNEW_NORM2] = t + red_step[4]; publish_ticket(hsc, seq); }
 }
 int ba_xnorm_partial(sfm_ctx* h, sfm_ba_problem p, const double* x) {
   Lay L; int rc = check_problem(h, p, &L); if (rc) return rc;
@@ -3667,7 +3683,7 @@ int ba_xnorm_partial(sfm_ctx* h, sfm_ba_problem p, const double* x) {
 int ba_xnorm_finish(sfm_ctx* h, sfm_ba_problem p, const double* x) {
   Lay L; int rc = check_problem(h, p, &L); if (rc) return rc;
   double* ws = (double*)p->workspace;
-  hipLaunchKernelGGL(k_xnorm_finish, dim3(1), dim3(256), 0, h->stream, p->n_cams * p->cam_dim, x, WS(L, red_step), WS(L, scalars), p->host_sc);
+  hipLaunchKernelGGL(k_xnorm_finish, dim3(1), dim3(256), 0, h->stream, p->n_cams * p->cam_dim, x, WS(L, red_step), WS(L, scalars), p->host_sc, next_ticket(p));
   SFM_LAUNCH_CHECK(h, "ba_xnorm_finish");
   return SFM_OK;
 }
@@ -3678,7 +3694,30 @@ extern "C" int sfm_ba_read_scalars(sfm_handle h, sfm_ba_problem p, double* out_h
   // every kernel that writes one of the scalars writes it into the problem's pinned host mirror too (p->host_sc): waiting for
   // the stream is all that is left to do here - the 128-byte device-to-host copy was a blit kernel of its own in front of every
   // one of these waits
-  SFM_HIP(h, hipStreamSynchronize(h->stream));
+  // ... and not even that: the finishing kernel of the stage publishes its ticket behind the scalars, and the host spins on the
+  // ticket word of the pinned page - it sees the scalars ~1 us after the kernel's last store, where a stream synchronisation
+  // returns only after the kernel has been retired and its completion signal processed.  Every SPIN_QUERY spins the
+  // stream is asked as well: a drained stream ends the wait whatever was published (a path that publishes nothing).
+  // SFM_POLL_SCALARS=0: wait for the stream.
+  {
+    static const bool poll_on = !(getenv("SFM_POLL_SCALARS") && getenv("SFM_POLL_SCALARS")[0] == '0');
+    bool seen = false;
+    if (poll_on && p->look_pending) {
+      volatile double* seq = p->host_sc + SFM_HSC_SEQ;
+      const double want = p->look_seq;
+      constexpr unsigned SPIN_QUERY = 4096;
+      for (unsigned spins = 1; ; ++spins) {
+        if (*seq == want) { seen = true; break; }
+        if ((spins % SPIN_QUERY) == 0 && hipStreamQuery(h->stream) != hipErrorNotReady) break;     // drained, or failed: the synchronisation below reports it
+#if defined(__x86_64__)
+        __builtin_ia32_pause();
+#endif
+      }
+      std::atomic_thread_fence(std::memory_order_acquire);
+    }
+    p->look_pending = 0;
+    if (!seen) SFM_HIP(h, hipStreamSynchronize(h->stream));
+  }
   if (p->cg2_pending) {
     // the verdict of the persistent CG on the second system of the last damped solve (sfm_ba_finish_solve) arrived with this
     // synchronisation; if that system did not converge - or its launch was abandoned - the q term is redone from the
@@ -3689,8 +3728,8 @@ extern "C" int sfm_ba_read_scalars(sfm_handle h, sfm_ba_problem p, double* out_h
       // (a relaunch finds the same inputs: r~2 is still in cg_r, S~ in the factor's buffer)
       const int C = p->n_cams, D = p->cam_dim, n = C * D;
       DenseWs dw; dense_ws_carve(WS(L, dense), n, &dw);
-      PrFuse fuse = {WS(L, cg_Minv), nullptr, nullptr, WS(L, pc), WS(L, red_q), WS(L, scalars), p->host_sc, 1};
-      const PrLaunch pl = {n, D, dw.Lm, WS(L, cg_r), nullptr, WS(L, cg_z), WS(L, cg_mail), WS(L, cg_scal), CGS_RTOL, fuse, p->host_sc + SFM_SC_COUNT, 1};
+      PrFuse fuse = {WS(L, cg_Minv), nullptr, nullptr, WS(L, pc), WS(L, red_q), WS(L, scalars), p->host_sc, 1, p->look_seq};
+      const PrLaunch pl = {n, D, dw.Lm, WS(L, cg_r), nullptr, WS(L, cg_z), WS(L, cg_mail), WS(L, cg_scal), CGS_RTOL, fuse, p->host_sc + SFM_HSC_CG2, 1};
       rc = cgs_persist_verdict(h, pl, p->sharded, &p->cg_iters, &status, &ran, &relaunched);
       if (rc) return rc;
     }

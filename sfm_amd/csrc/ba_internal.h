@@ -38,6 +38,12 @@ struct sfm_ba_prob {
   double* host_sc;           // pinned host mirror of the SFM_SC_* scalars (written by the kernels that write them; sfm_ba_read_scalars),
                              // followed by the 8 status words of THIS problem's pending second-system CG (a slot per problem: two
                              // problems on one handle may both have a verdict in flight between finish_solve and read_scalars)
+  // sfm_ba_read_scalars waits for a TICKET instead of for the stream: the kernel that finishes a stage (k_finish_linearize /
+  // _solve / _solve_pcg / _step, k_xnorm_finish, the epilogue of the persistent CG's second system) writes the scalars into the
+  // pinned mirror and, behind a system-scope fence, the ticket it was launched with into word SFM_HSC_SEQ of the same page; the
+  // host spins on that word.  look_seq: the last ticket handed out; look_pending: a ticket is out and has not been waited for.
+  double look_seq;
+  int look_pending;
   int sharded;               // this problem is one rank's shard of a multi-rank solve (sfm_ba_set_sharded, or a reduce hook given to
                              // the loop / sfm_ba_solve_pcg): a route whose choice could differ between ranks is never switched locally
   int cg_scal_clean;         // sfm_ba_schur_build has just cleared the CG status words (sfm_ba_schur_solve then skips its memset)
@@ -66,6 +72,12 @@ struct sfm_ba_prob {
   int warm_pc_ok, warm_qc_ok;
   double warm_alpha;
 };
+
+// layout of the pinned page host_sc: the SFM_SC_* scalars, the 8 status words of the pending second-system CG, the ticket
+constexpr int SFM_HSC_CG2 = SFM_SC_COUNT, SFM_HSC_SEQ = SFM_SC_COUNT + 8, SFM_HSC_WORDS = SFM_SC_COUNT + 16;
+
+// the ticket the finishing kernel of a stage is launched with (sfm_ba_read_scalars)
+static inline double next_ticket(sfm_ba_prob* p) { p->look_seq += 1.0; p->look_pending = 1; return p->look_seq; }
 
 Lay ba_layout(int64_t C, int64_t P, int64_t N, int64_t D, int64_t n_items, int64_t n_cchunks, int precision);
 

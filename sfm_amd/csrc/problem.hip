@@ -203,11 +203,11 @@ extern "C" int sfm_ba_create_problem(sfm_handle h, const sfm_ba_desc* d, sfm_ba_
   p->camera_solver = d->camera_solver;
   p->einv_alpha = -1.0; p->st_alpha = -1.0; p->s_valid = 1;
   // pinned host mirror of the scalars (every kernel that writes one writes it here too: sfm_ba_read_scalars only waits)
-  if (hipHostMalloc((void**)&p->host_sc, (SFM_SC_COUNT + 8) * sizeof(double), hipHostMallocDefault) != hipSuccess) {
+  if (hipHostMalloc((void**)&p->host_sc, SFM_HSC_WORDS * sizeof(double), hipHostMallocDefault) != hipSuccess) {
     p->host_sc = nullptr; sfm_ba_destroy_problem(p);
     return sfm_fail(h, SFM_ERR_HIP, "sfm_ba_create_problem", "pinned host memory for the scalars");
   }
-  memset(p->host_sc, 0, (SFM_SC_COUNT + 8) * sizeof(double));
+  memset(p->host_sc, 0, SFM_HSC_WORDS * sizeof(double));
   p->n_obs = N;
   p->fx0 = d->fx0; p->fy0 = d->fy0; p->cx0 = d->cx0; p->cy0 = d->cy0;
   p->width = d->width; p->height = d->height; p->reg_weight = d->reg_weight;
