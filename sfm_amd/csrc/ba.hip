@@ -27,13 +27,15 @@
 
 typedef double v4d __attribute__((ext_vector_type(4)));
 
-// the ticket of a finished stage into the pinned page, BEHIND the scalars (sfm_ba_read_scalars spins on it); seq 0: none
-__device__ __forceinline__ void publish_ticket(double* hsc, double seq) {
+// a ticket into a pinned host word, BEHIND everything this thread has written before (the host spins on the word); seq 0: none
+__device__ __forceinline__ void publish_word(double* word, double seq) {
   if (seq > 0.0) {
     __threadfence_system();
-    *(volatile double*)(hsc + SFM_HSC_SEQ) = seq;
+    *(volatile double*)word = seq;
   }
 }
+// the ticket of a finished stage into the problem's pinned page, behind the scalars (sfm_ba_read_scalars)
+__device__ __forceinline__ void publish_ticket(double* hsc, double seq) { publish_word(hsc + SFM_HSC_SEQ, seq); }
 
 #define EPS_D 2.220446049250313e-16
 #define SQRT_EPS_D 1.4901161193847656e-08
@@ -2804,7 +2806,8 @@ __global__ __launch_bounds__(256) void k_cgb_init(int n, int nbp, const double* 
 }
 __global__ __launch_bounds__(256) void k_cgb_symv(int n, int nb, int nbp, int it, double rtol2, const double* __restrict__ St,
                                                   double* __restrict__ vec, const double* __restrict__ wv, const double* __restrict__ dots,
-                                                  double* __restrict__ P, double* __restrict__ scal, double* __restrict__ x_out, int flip) {
+                                                  double* __restrict__ P, double* __restrict__ scal, double* __restrict__ x_out, int flip,
+                                                  double* __restrict__ hst /* pinned host words */, double seq) {
   // CGS_DONE holds 1 + the index of the launch that saw the end (converged or broken).  Only an EARLIER launch's verdict stops
   // this one: the tiles of the deciding launch itself all reach the same verdict from the same numbers, and each still has its
   // range of x to copy out - a tile that started late must not take tile 0's freshly written flag for yesterday's
@@ -2866,6 +2869,15 @@ __global__ __launch_bounds__(256) void k_cgb_symv(int n, int nb, int nbp, int it
       scal[CGS_RR] = g; scal[CGS_ITER] = (double)(it - 1);
       if (converged || broken) scal[CGS_DONE] = (double)(it + 1);
       if (broken) scal[CGS_FAIL] = 2.0;
+      // the host's copy, straight into its pinned page: where the solve stands (every launch) and, from the launch that sees the
+      // end, the verdict with the system's ticket behind it - cgs_solve_big spins on the ticket and goes on enqueuing while the
+      // launches it had queued blind behind this one are still returning
+      const double fl = broken ? 2.0 : scal[CGS_FAIL];
+      hst[CGS_RR0] = g0; hst[CGS_RR] = g; hst[CGS_ITER] = (double)(it - 1); hst[CGS_FAIL] = fl;
+      if (converged || broken) {
+        hst[CGS_DONE] = (double)(it + 1);
+        publish_word(hst + 7, seq);
+      }
     }
     if (converged) {                                 // (uniform over the whole grid) x_{it-1} is the answer
       if (own && gi < n) x_out[gi] = v_x;
@@ -2971,18 +2983,40 @@ static int cgs_solve_big(sfm_ctx* h, int n, const double* St, const double* rhs_
   int it = 0;
   int batch = its_hint > 0 ? (its_hint + 4 > 48 ? 48 : its_hint + 4) : 24;
   const int budget = cgs_big_budget();
+  // The verdict comes through the pinned page (k_cgb_symv): the host spins on this system's ticket and, every SPIN_QUERY spins,
+  // asks whether the stream has drained (a batch that ended without a verdict).  No status copy, no stream synchronisation
+  // on the way of a system that converges within its batch - and the caller's next launches queue up behind the blind launches
+  // still returning.  (No launch of an earlier system can write here: all of them return at their first instruction.)
+  volatile double* hst = h->pinned + SFM_PIN_CGB;
+  h->cgb_seq += 1.0;
+  const double seq = h->cgb_seq;
+  for (int q = 0; q < 7; ++q) hst[q] = 0.0;
+  constexpr unsigned SPIN_QUERY = 4096;
   while (it < budget + 2) {
     for (int b = 0; b < batch && it < budget + 2; ++b, ++it) {
-      hipLaunchKernelGGL(k_cgb_symv, dim3(n_tiles), dim3(256), 0, h->stream, n, nb, nbp, it, rtol2, St, vec, wv, dots, P, scal, x_t, zigzag == 1 ? (it & 1) : (zigzag == 2 ? ((it + 1) & 1) : 0));
+      hipLaunchKernelGGL(k_cgb_symv, dim3(n_tiles), dim3(256), 0, h->stream, n, nb, nbp, it, rtol2, St, vec, wv, dots, P, scal, x_t, zigzag == 1 ? (it & 1) : (zigzag == 2 ? ((it + 1) & 1) : 0),
+                         h->pinned + SFM_PIN_CGB, seq);
       hipLaunchKernelGGL(k_cgb_reduce, dim3(nb), dim3(128), 0, h->stream, n, nb, nbp, it, P, vec, wv, dots, scal);
     }
-    SFM_HIP(h, hipMemcpyAsync(h->pinned, scal, 8 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
-    SFM_HIP(h, hipStreamSynchronize(h->stream));
-    if (h->pinned[CGS_FAIL] != 0.0) break;
-    if (h->pinned[CGS_DONE] != 0.0) { *status = 0; break; }          // (the launch that saw it has copied x out)
-    const double rr = h->pinned[CGS_RR], rr0 = h->pinned[CGS_RR0];
+    bool seen = false;
+    for (unsigned spins = 1; ; ++spins) {
+      if (hst[7] == seq) { seen = true; break; }
+      if ((spins % SPIN_QUERY) == 0 && hipStreamQuery(h->stream) != hipErrorNotReady) break;
+#if defined(__x86_64__)
+      __builtin_ia32_pause();
+#endif
+    }
+    std::atomic_thread_fence(std::memory_order_acquire);
+    if (!seen) {
+      SFM_HIP(h, hipStreamSynchronize(h->stream));
+      seen = hst[7] == seq;                           // (the verdict of the batch's last launches)
+    }
+    if (seen && hst[CGS_FAIL] != 0.0) break;
+    if (seen) { *status = 0; break; }                 // (the launch that saw the end has copied x out)
+    if (hst[CGS_FAIL] != 0.0) break;                  // a diagonal block was not positive definite (raised before the first launch)
+    const double rr = hst[CGS_RR], rr0 = hst[CGS_RR0];
     // next look where the residual should be small enough, from the average rate so far (as cgs_solve)
-    const double done_its = h->pinned[CGS_ITER] > 1.0 ? h->pinned[CGS_ITER] : 1.0;
+    const double done_its = hst[CGS_ITER] > 1.0 ? hst[CGS_ITER] : 1.0;
     const double rate = rr0 > 0.0 ? std::log(rr / rr0) / done_its : 0.0;
     batch = 8;
     if (rate < -1e-3 && rr > 0.0) {
@@ -2990,7 +3024,7 @@ static int cgs_solve_big(sfm_ctx* h, int n, const double* St, const double* rhs_
       batch = need < 2.0 ? 3 : (need > 48.0 ? 48 : (int)need + 3);
     }
   }
-  *iters_out += (int)h->pinned[CGS_ITER];
+  *iters_out += (int)hst[CGS_ITER];
   SFM_LAUNCH_CHECK(h, "cgs_solve_big");
   return SFM_OK;
 }

@@ -9,6 +9,7 @@
 #define SFM_PROF_RING 128
 #define SFM_PINNED_DOUBLES 64
 #define SFM_PIN_CG1 32
+#define SFM_PIN_CGB 40       /* tile-streaming CG: its status words as the deciding launch writes them, word 7 = the system's ticket */
 struct sfm_prof_slot {
   hipEvent_t start[SFM_PROF_RING], stop[SFM_PROF_RING];
   int pending;             // recorded, not yet folded into total_ms
@@ -32,6 +33,7 @@ struct sfm_ctx {
   int comm_owned, comm_ranks, comm_rank;
   int cgs_persist_off;     // set once a persistent CG launch had to be abandoned: per-launch kernel from then on
   int cgs_xcd_off;         // set once a one-XCD launch of the persistent CG had to be abandoned: device-wide form from then on
+  double cgb_seq;          // tickets of the tile-streaming CG's systems (cgs_solve_big spins on word SFM_PIN_CGB + 7)
 };
 
 // HIP-event bracket around one kernel (or one short kernel sequence) on the handle's stream.
