@@ -592,16 +592,10 @@ __global__ __launch_bounds__(256) void k_finish_linearize(int n, const double* _
 
 // ------------------------------------------------------------------------------------ damped solve: point side
 // L_j L_j^T = C_j + alpha I ; stores M = L_j^-1 (lower, packed m00 m10 m11 m20 m21 m22) and e_j = M g_pj.
-__global__ void k_point_factor(int P, double alpha, const double* __restrict__ Cp,
-                               const double* __restrict__ gp, double* __restrict__ Linv,
-                               double* __restrict__ e, double* __restrict__ cg_scal = nullptr) {
-  // the status and ticket words of the camera CG that follows start from zero: cleared HERE, by the first kernel of
-  // sfm_ba_schur_build, instead of by a memset between two kernels of the chain (a fill kernel of its own, ~5 us with its
-  // boundaries) - and before k_schur_assemble, whose diagonal-block workgroups may RAISE the failure word
-  if (cg_scal && blockIdx.x == 0 && threadIdx.x < 64) cg_scal[threadIdx.x] = 0.0;
-  const int j = blockIdx.x * blockDim.x + threadIdx.x;
-  if (j >= P) return;
-  const double* c = Cp + (size_t)j * 6;
+// M = L^-1 (packed m00 m10 m11 m20 m21 m22) of L L^T = C_j + alpha I, and e_j = M g_pj: the SAME statements wherever a kernel needs
+// them (k_build_G forms them per observation instead of fetching what a kernel of its own had stored)
+__device__ __forceinline__ void point_factor_vals(const double* __restrict__ c, const double* __restrict__ g, double alpha,
+                                                  double (&m)[6], double (&ev)[3]) {
   const double a00 = c[0] + alpha, a10 = c[1], a20 = c[2], a11 = c[3] + alpha, a21 = c[4], a22 = c[5] + alpha;
   const double l00 = sqrt(a00), l10 = a10 / l00, l20 = a20 / l00;
   const double l11 = sqrt(a11 - l10 * l10), l21 = (a21 - l20 * l10) / l11;
@@ -609,12 +603,11 @@ __global__ void k_point_factor(int P, double alpha, const double* __restrict__ C
   const double m00 = 1.0 / l00, m11 = 1.0 / l11, m22 = 1.0 / l22;
   const double m10 = -l10 * m00 * m11, m21 = -l21 * m11 * m22;
   const double m20 = -(l20 * m00 + l21 * m10) * m22;
-  double* o = Linv + (size_t)j * 6;
-  o[0] = m00; o[1] = m10; o[2] = m11; o[3] = m20; o[4] = m21; o[5] = m22;
-  const double g0 = gp[(size_t)j * 3], g1 = gp[(size_t)j * 3 + 1], g2 = gp[(size_t)j * 3 + 2];
-  e[(size_t)j * 3] = m00 * g0;
-  e[(size_t)j * 3 + 1] = m10 * g0 + m11 * g1;
-  e[(size_t)j * 3 + 2] = m20 * g0 + m21 * g1 + m22 * g2;
+  m[0] = m00; m[1] = m10; m[2] = m11; m[3] = m20; m[4] = m21; m[5] = m22;
+  const double g0 = g[0], g1 = g[1], g2 = g[2];
+  ev[0] = m00 * g0;
+  ev[1] = m10 * g0 + m11 * g1;
+  ev[2] = m20 * g0 + m21 * g1 + m22 * g2;
 }
 
 // G_k[m][a] = sum_r Jc~[r][a] * V[r][m],  V = Jp~ M^T (2x3); e_j copied next to the observation (k_schur_items, diagonal
@@ -627,9 +620,31 @@ __global__ void k_point_factor(int P, double alpha, const double* __restrict__ C
 template <int D, typename T, typename TG, int GS>
 __global__ __launch_bounds__(256) void k_build_G(int64_t N, const int* __restrict__ pt_idx,
                                                  const T* __restrict__ recA, const T* __restrict__ recB,
-                                                 const double* __restrict__ Linv, TG* __restrict__ G,
-                                                 const double* __restrict__ e, double* __restrict__ eobs) {
+                                                 double* __restrict__ Linv, TG* __restrict__ G,
+                                                 double* __restrict__ e, double* __restrict__ eobs,
+                                                 const double* __restrict__ Cp, const double* __restrict__ gp, double alpha, int P,
+                                                 unsigned nblk_obs, double* __restrict__ cg_scal /* may be null */) {
   static_assert(GS % 2 == 0 && GS >= 3 * D, "G blocks are written as 16-byte pieces");
+  // the status and ticket words of the camera CG that follows start from zero: cleared HERE, by the first kernel of
+  // sfm_ba_schur_build, instead of by a memset between two kernels of the chain (a fill kernel of its own, ~5 us with its
+  // boundaries) - and before k_schur_assemble, whose diagonal-block workgroups may RAISE the failure word
+  if (cg_scal && blockIdx.x == 0 && threadIdx.x < 64) cg_scal[threadIdx.x] = 0.0;
+  // The point factors M_j = L_j^-1 and e_j = M_j g_pj for the kernels further down the chain (k_backsub, the camera-wise passes)
+  // are the work of the LAST cdiv(P, 256) workgroups of this launch - a kernel of its own until round 4 (k_point_factor: 6 us
+  // and a boundary in front of every damped solve).  The observation workgroups do not wait for them: every observation forms
+  // its point's M and e itself, from the same six + three doubles by the same statements (point_factor_vals).
+  if (blockIdx.x >= nblk_obs) {
+    const int j = (int)(blockIdx.x - nblk_obs) * 256 + (int)threadIdx.x;
+    if (j < P) {
+      double m[6], ev[3];
+      point_factor_vals(Cp + (size_t)j * 6, gp + (size_t)j * 3, alpha, m, ev);
+#pragma unroll
+      for (int q = 0; q < 6; ++q) Linv[(size_t)j * 6 + q] = m[q];
+#pragma unroll
+      for (int q = 0; q < 3; ++q) e[(size_t)j * 3 + q] = ev[q];
+    }
+    return;
+  }
   constexpr int WA = 2 * D, LDA = WA + 1, LDB = 9, LDG = GS + 1;
   constexpr int VE = 16 / (int)sizeof(T);                // elements per 16-byte load
   constexpr int NA = WA / VE, NB = 8 / VE;               // 16-byte loads per thread for the two record arrays of 256 observations
@@ -655,9 +670,11 @@ __global__ __launch_bounds__(256) void k_build_G(int64_t N, const int* __restric
 #pragma unroll
     for (int j = 0; j < NB; ++j) { const int i = tid + 256 * j; lb[j] = i * VE < nvalid * 8 ? inB[i] : (vec_t)(T)0; }
   }
-  const double* M = Linv + (size_t)pj * 6;
-  const double m00 = M[0], m10 = M[1], m11 = M[2], m20 = M[3], m21 = M[4], m22 = M[5];
-  const double e0 = e[pj * 3], e1 = e[pj * 3 + 1], e2 = e[pj * 3 + 2];
+  double cpj[6], gpj[3];
+#pragma unroll
+  for (int q = 0; q < 6; ++q) cpj[q] = Cp[(size_t)pj * 6 + q];
+#pragma unroll
+  for (int q = 0; q < 3; ++q) gpj[q] = gp[(size_t)pj * 3 + q];
 #pragma unroll
   for (int j = 0; j < NA; ++j)
 #pragma unroll
@@ -667,6 +684,10 @@ __global__ __launch_bounds__(256) void k_build_G(int64_t N, const int* __restric
 #pragma unroll
     for (int v = 0; v < VE; ++v) { const int i = (tid + 256 * j) * VE + v; s_jp[(i >> 3) * LDB + (i & 7)] = (double)lb[j][v]; }
   __syncthreads();
+  double mq[6], eq[3];
+  point_factor_vals(cpj, gpj, alpha, mq, eq);
+  const double m00 = mq[0], m10 = mq[1], m11 = mq[2], m20 = mq[3], m21 = mq[4], m22 = mq[5];
+  const double e0 = eq[0], e1 = eq[1], e2 = eq[2];
   double g[3 * D];
   {
     const double* jp = &s_jp[tid * LDB];
@@ -1771,11 +1792,10 @@ extern "C" int sfm_ba_schur_build(sfm_handle h, sfm_ba_problem p, double alpha) 
   const int C = p->n_cams, P = p->n_pts, D = p->cam_dim, n = C * D;
   const int64_t N = p->n_obs;
   sfm_prof_begin(h, SFM_PROF_BUILD_G);
-  hipLaunchKernelGGL(k_point_factor, dim3(cdiv(P, 256)), dim3(256), 0, h->stream, P, alpha, WS(L, Cp), WS(L, gp),
-                     WS(L, Linv), WS(L, e), WS(L, cg_scal));
   DISPATCH_DT(D, p->precision, {
-    hipLaunchKernelGGL((k_build_G<DD, TT, double, GG>), dim3(cdiv(N, 256)), dim3(256), 0, h->stream, N, p->pt_idx, WST(L, recA),
-                       WST(L, recB), WS(L, Linv), WS(L, G), WS(L, e), WS(L, eobs));
+    hipLaunchKernelGGL((k_build_G<DD, TT, double, GG>), dim3(cdiv(N, 256) + cdiv(P, 256)), dim3(256), 0, h->stream, N, p->pt_idx, WST(L, recA),
+                       WST(L, recB), WS(L, Linv), WS(L, G), WS(L, e), WS(L, eobs), WS(L, Cp), WS(L, gp), alpha, P, (unsigned)cdiv(N, 256),
+                       WS(L, cg_scal));
     sfm_prof_end(h, SFM_PROF_BUILD_G);
     sfm_prof_begin(h, SFM_PROF_SCHUR);
     if (p->n_items > 0) { // 8 groups x ceil(largest group / 4) workgroups
@@ -3588,10 +3608,10 @@ extern "C" int sfm_ba_solve_pcg(sfm_handle h, sfm_ba_problem p, double alpha, in
   SFM_HIP(h, hipMemsetAsync(WS(L, cg_scal), 0, 64 * sizeof(double), h->stream));
   // point factors, G, and this rank's part of the right-hand side r = g_c - W C_a^-1 g_p and of the diagonal blocks
   sfm_prof_begin(h, SFM_PROF_BUILD_G);
-  hipLaunchKernelGGL(k_point_factor, dim3(cdiv(P, 256)), dim3(256), 0, h->stream, P, alpha, WS(L, Cp), WS(L, gp), WS(L, Linv), WS(L, e));
   DISPATCH_DT(D, p->precision, {
-    hipLaunchKernelGGL((k_build_G<DD, TT, double, GG>), dim3(cdiv(N, 256)), dim3(256), 0, h->stream, N, p->pt_idx, WST(L, recA),
-                       WST(L, recB), WS(L, Linv), WS(L, G), WS(L, e), WS(L, eobs));
+    hipLaunchKernelGGL((k_build_G<DD, TT, double, GG>), dim3(cdiv(N, 256) + cdiv(P, 256)), dim3(256), 0, h->stream, N, p->pt_idx, WST(L, recA),
+                       WST(L, recB), WS(L, Linv), WS(L, G), WS(L, e), WS(L, eobs), WS(L, Cp), WS(L, gp), alpha, P, (unsigned)cdiv(N, 256),
+                       (double*)nullptr);
     sfm_prof_end(h, SFM_PROF_BUILD_G);
     sfm_prof_begin(h, SFM_PROF_SCHUR);
     if (p->n_cchunks > 0) {
