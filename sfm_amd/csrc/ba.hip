@@ -831,7 +831,7 @@ __global__ __launch_bounds__(64 * SFM_SCHUR_WG_WAVES) __attribute__((amdgpu_wave
   constexpr int U = (64 + BPL - 1) / BPL < UMAX ? (64 + BPL - 1) / BPL : UMAX;   // load instructions in flight per operand
   constexpr int PB = U * BPL;                  // pairs per batch
   constexpr int WGW = SFM_SCHUR_WG_WAVES;
-  __shared__ __attribute__((aligned(16))) char s_stage[WGW][2][BPL * BB];
+  __shared__ __attribute__((aligned(16))) char s_stage[WGW][2][BPL * BB + 16];   // + a slot that always reads as zero
   __shared__ double s_e[WGW][64][3];           // diagonal items: e_j of the 64 pairs whose ids the wave holds
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   // workgroup b serves item group b % 8 (a set of whole block rows, problem.hip): with the round-robin XCD placement one
@@ -841,8 +841,10 @@ __global__ __launch_bounds__(64 * SFM_SCHUR_WG_WAVES) __attribute__((amdgpu_wave
   const int pos = xcd_ptr[grp] + (blockIdx.x >> 3) * WGW + w;
   if (pos >= xcd_ptr[grp + 1]) return;
   SCHUR_STAMP_BEGIN();
-  const int it = xcd_items[pos];
-  const int beg = item_beg[it], end = item_end[it];
+  // (the item and its bounds are the same for the whole wave: in SGPRs, so that every loop bound below is scalar - as per-lane
+  // loads they put the trip count of the MFMA loop into a VGPR and an exec-mask dance around every MFMA)
+  const int it = __builtin_amdgcn_readfirstlane(xcd_items[pos]);
+  const int beg = __builtin_amdgcn_readfirstlane(item_beg[it]), end = __builtin_amdgcn_readfirstlane(item_end[it]);
   const int row = lane & 15, m = lane >> 4;
   const bool valid = (row < D) && (m < 3);
   const int off = valid ? m * D + row : 0;
@@ -860,12 +862,16 @@ __global__ __launch_bounds__(64 * SFM_SCHUR_WG_WAVES) __attribute__((amdgpu_wave
   // K-packed form (see the MFMA loop): slot s = 4 j + m of MFMA j -> pair s / 3 of the slab, point coordinate s % 3
   constexpr int NM = (3 * BPL + 3) / 4;                   // MFMAs per full slab (3 for 4 pairs, 6 for 7)
   const bool krow = row < D, ke_lane = row == D;
-  int koff[NM];                                           // LDS element of this lane's slot in MFMA j; < 0: beyond the slab (reads as zero)
+  // LDS element of this lane's slot in MFMA j; lanes without one (row >= D, or a slot beyond the slab) read the slab's ZERO SLOT:
+  // an unconditional ds_read where a predicated one cost an exec-masked block with its zero fill per operand
+  constexpr int ZSLOT = BPL * GS;
+  int koff[NM];
 #pragma unroll
   for (int j = 0; j < NM; ++j) {
     const int sl = 4 * j + m, pi = (sl * 11) >> 5;        // sl / 3 for sl < 32
-    koff[j] = (pi < BPL && krow) ? pi * GS + (sl - 3 * pi) * D + row : -1;
+    koff[j] = (pi < BPL && krow) ? pi * GS + (sl - 3 * pi) * D + row : ZSLOT;
   }
+  if (lane < 2) { ((double*)sA)[ZSLOT + lane] = 0.0; ((double*)sB)[ZSLOT + lane] = 0.0; }
   // two instantiations of the item loop (the off-diagonal one is the kernel as it was: nothing of the diagonal path in it)
   auto run = [&](auto diag_c) __attribute__((always_inline)) {
     constexpr bool DIAG = decltype(diag_c)::value;
@@ -883,6 +889,9 @@ __global__ __launch_bounds__(64 * SFM_SCHUR_WG_WAVES) __attribute__((amdgpu_wave
       }
       for (int u0 = 0; u0 < cnt; u0 += PB) {
         chunk_t ra[U], rb[U];
+        // (Measured and not kept: every lane loading unconditionally, surplus lanes fetching the item's last pair again - 292
+        // against 287 us; G through a buffer resource with 32-bit offsets and zeros beyond the end, all 16 loads back to back -
+        // 295: tools/experiments/README.md.)
 #pragma unroll
         for (int t = 0; t < U; ++t) {
           const int p = u0 + t * BPL + lb;                  // pair this lane fetches a chunk of
@@ -908,20 +917,33 @@ __global__ __launch_bounds__(64 * SFM_SCHUR_WG_WAVES) __attribute__((amdgpu_wave
           if (KPACK) {
             // the contraction index of a slab is (pair, m): 3 nb slots for nb pairs, 4 per MFMA - four pairs = 12 slots = 3 FULL
             // v_mfma_f64_16x16x4 instead of 4 with K = 3 of 4 used.  Slot s = 4 j + (lane >> 4) of MFMA j reads pair s / 3,
-            // m = s % 3 (offsets precomputed per lane: koff[j]); pairs past the end of the item were stored as zeros
+            // m = s % 3 (offsets precomputed per lane: koff[j]); pairs past the end of the item were stored as zeros.
+            // ALL operands of the slab are read before the first MFMA (one LDS latency per slab, not one per MFMA).
             const int nb = (cnt - (u0 + t * BPL)) < BPL ? (cnt - (u0 + t * BPL)) : BPL;
             const int nm = (3 * nb + 3) >> 2;
+            // (d = 6 runs at 8 waves per SIMD on 64 registers: its six MFMAs per slab take their operands one at a time)
+            constexpr int PFN = D == 6 ? 1 : NM;
 #pragma unroll
-            for (int j = 0; j < NM; ++j) {
-              if (j >= nm) break;                             // wave-uniform
-              const bool in = koff[j] >= 0;
-              const double a = in ? (double)((const T*)sA)[koff[j]] : 0.0;
-              double b;
-              if (DIAG) {
-                const int sl = 4 * j + m, pi = (sl * 11) >> 5;
-                b = in ? a : ((ke_lane && pi < nb) ? s_e[w][u0 + t * BPL + pi][sl - 3 * pi] : 0.0);
-              } else b = in ? (double)((const T*)sB)[koff[j]] : 0.0;
-              acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
+            for (int j0 = 0; j0 < NM; j0 += PFN) {
+              if (j0 >= nm) break;                            // wave-uniform
+              double av[PFN], bv[PFN];
+#pragma unroll
+              for (int q = 0; q < PFN; ++q) {
+                const int j = j0 + q;
+                if (j < NM) {
+                  const int ko = koff[j];
+                  av[q] = (double)((const T*)sA)[ko];
+                  if (DIAG) {
+                    const int sl = 4 * j + m, pi = (sl * 11) >> 5;
+                    bv[q] = ko != ZSLOT ? av[q] : ((ke_lane && pi < nb) ? s_e[w][u0 + t * BPL + pi][sl - 3 * pi] : 0.0);
+                  } else bv[q] = (double)((const T*)sB)[ko];
+                }
+              }
+#pragma unroll
+              for (int q = 0; q < PFN; ++q) {
+                if (j0 + q >= nm || j0 + q >= NM) break;      // wave-uniform
+                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[q], bv[q], acc, 0, 0, 0);
+              }
             }
           } else {
 #pragma unroll
