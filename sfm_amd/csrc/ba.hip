@@ -1292,13 +1292,27 @@ __global__ __launch_bounds__(256) void k_cam_reduce_chunks(const int* __restrict
   const int m = live ? e0 / D : 0;
   double acc0 = 0.0, acc1 = 0.0;
   const int beg = cch_beg[ch], end = cch_end[ch];
-  for (int i = beg + w * 4 + grp; i < end; i += 16) {
-    const int k = cam_obs[i];
-    const double vm = vec[(size_t)pt_idx[k] * 3 + m];
-    if (live) {
-      const pair_t g = *(const pair_t*)(G + (size_t)k * GS + e0);
-      acc0 += (double)g.x * vm; acc1 += (double)g.y * vm;
+  // A trip is a chain of three dependent loads (observation id -> its point -> the point's vector, the G piece beside the point
+  // id), and with a run-time trip count each trip waited for the one before: 16 chains one after the other per 256-observation
+  // chunk - the launch was as long as that (60 us at 200 cameras for 256 MB).  Four trips' loads are now issued level by level;
+  // the products are still added in trip order (the same bits).
+  constexpr int UNR = 4;
+  for (int i0 = beg + w * 4 + grp; i0 < end; i0 += 16 * UNR) {
+    int k[UNR], pj[UNR];
+    pair_t g[UNR];
+    double vm[UNR];
+#pragma unroll
+    for (int u = 0; u < UNR; ++u) { const int i = i0 + 16 * u; k[u] = i < end ? cam_obs[i] : -1; }
+#pragma unroll
+    for (int u = 0; u < UNR; ++u) {
+      pj[u] = k[u] >= 0 ? pt_idx[k[u]] : 0;
+      g[u] = (k[u] >= 0 && live) ? *(const pair_t*)(G + (size_t)k[u] * GS + e0) : (pair_t){(T)0, (T)0};
     }
+#pragma unroll
+    for (int u = 0; u < UNR; ++u) vm[u] = k[u] >= 0 ? vec[(size_t)pj[u] * 3 + m] : 0.0;
+#pragma unroll
+    for (int u = 0; u < UNR; ++u)
+      if (k[u] >= 0 && live) { acc0 += (double)g[u].x * vm[u]; acc1 += (double)g[u].y * vm[u]; }
   }
   s[w][grp][e0] = acc0; s[w][grp][e0 + 1] = acc1;
   __syncthreads();
