@@ -892,6 +892,21 @@ __global__ __launch_bounds__(64 * SFM_SCHUR_WG_WAVES) __attribute__((amdgpu_wave
         // (Measured and not kept: every lane loading unconditionally, surplus lanes fetching the item's last pair again - 292
         // against 287 us; G through a buffer resource with 32-bit offsets and zeros beyond the end, all 16 loads back to back -
         // 295: tools/experiments/README.md.)
+        if (u0 + PB <= cnt) {
+          // a FULL batch (the usual case: every batch of a 256-pair item but perhaps its last): every pair exists, so no load
+          // needs its predicate - no exec-masked block around each of the 16 loads (the one lane beyond the last block of a
+          // load, d = 6, fetches that block's neighbour once more and does not store it)
+#pragma unroll
+          for (int t = 0; t < U; ++t) {
+            const int p = u0 + t * BPL + (loader ? lb : BPL - 1);
+            ra[t] = *(const chunk_t*)(Gb + (size_t)(unsigned)__shfl(kk, p, 64) * BB + 16 * lc);
+            if (!DIAG) {
+              const char* pb = Gb + (size_t)(unsigned)__shfl(kk2, p, 64) * BB + 16 * lc;
+              if (NTK2) rb[t] = __builtin_nontemporal_load((const chunk_t*)pb);
+              else rb[t] = *(const chunk_t*)pb;
+            }
+          }
+        } else
 #pragma unroll
         for (int t = 0; t < U; ++t) {
           const int p = u0 + t * BPL + lb;                  // pair this lane fetches a chunk of
