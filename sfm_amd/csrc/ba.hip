@@ -875,10 +875,16 @@ __global__ __launch_bounds__(64 * SFM_SCHUR_WG_WAVES) __attribute__((amdgpu_wave
   // two instantiations of the item loop (the off-diagonal one is the kernel as it was: nothing of the diagonal path in it)
   auto run = [&](auto diag_c) __attribute__((always_inline)) {
     constexpr bool DIAG = decltype(diag_c)::value;
+    // (the pair ids of the NEXT 64 pairs are asked for while the present 64 are worked on)
+    int kk_n = (beg + lane) < end ? pair_k[beg + lane] : 0;
+    int kk2_n = DIAG ? kk_n : ((beg + lane) < end ? pair_k2[beg + lane] : 0);
     for (int base = beg; base < end; base += 64) {
-      const int idx = base + lane;
-      const int kk = idx < end ? pair_k[idx] : 0;
-      const int kk2 = DIAG ? kk : (idx < end ? pair_k2[idx] : 0);
+      const int kk = kk_n, kk2 = kk2_n;
+      if (base + 64 < end) {                               // wave-uniform
+        const int idn = base + 64 + lane;
+        kk_n = idn < end ? pair_k[idn] : 0;
+        kk2_n = DIAG ? kk_n : (idn < end ? pair_k2[idn] : 0);
+      }
       const int cnt = (end - base) < 64 ? (end - base) : 64;
       if (DIAG) {
         // e_j of this lane's pair (the per-observation copy k_build_G leaves) -> LDS, in flight together with the G loads
