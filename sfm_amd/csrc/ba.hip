@@ -461,12 +461,23 @@ __global__ __launch_bounds__(256) void k_cam_blocks_chunks(const int* __restrict
   const int q = col < D ? rrow * D + col : 2 * D + rrow; // position inside an observation's staged record
   const bool live = col <= D;
   const int per = (cnt + 3) / 4;
-  const int o0 = w * per, o1 = (o0 + per) < cnt ? (o0 + per) : cnt;
+  // (the wave's range in SGPRs - w comes from threadIdx, so the compiler kept the trip count in a VGPR and wrapped every MFMA
+  // in an exec-mask save / restore - and four steps' operands read ahead of their MFMAs: one LDS wait per four, not per one)
+  const int wu = __builtin_amdgcn_readfirstlane(w);
+  const int o0 = wu * per, o1 = (o0 + per) < cnt ? (o0 + per) : cnt;
   v4d acc = {0.0, 0.0, 0.0, 0.0};
-  for (int o = o0; o < o1; o += 2) {                     // k slots: (o, row 0), (o, row 1), (o + 1, row 0), (o + 1, row 1)
-    const int oo = o + (kq >> 1);
-    const double v = (live && oo < o1) ? s[oo * LDW + q] : 0.0;
-    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(v, v, acc, 0, 0, 0);
+  for (int o = o0; o < o1; o += 8) {                     // k slots of a step: (o, row 0), (o, row 1), (o + 1, row 0), (o + 1, row 1)
+    double v[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int oo = o + 2 * u + (kq >> 1);
+      v[u] = (live && oo < o1) ? s[oo * LDW + q] : 0.0;
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      if (o + 2 * u >= o1) break;                          // wave-uniform
+      acc = __builtin_amdgcn_mfma_f64_16x16x4f64(v[u], v[u], acc, 0, 0, 0);
+    }
   }
 #pragma unroll
   for (int i = 0; i < 4; ++i) s_tile[w][(kq + 4 * i) * 17 + col] = acc[i];      // C/D: row = kq + 4 i, column = col
