@@ -2072,7 +2072,8 @@ __global__ __launch_bounds__(64) void k_diag_einv(int C, const double* __restric
 // block) per block row c and SCALE_NB consecutive columns c2; only the blocks c2 >= c are computed, each is written twice
 // (St is symmetric: the block and its transpose).  All blocks of a workgroup move through each stage together: three
 // barriers per workgroup, not per block.  (One workgroup per block pair, 40,000 at 200 cameras: 22 us, dispatch-bound.)
-constexpr int SCALE_NB = 8;
+// (blocks per workgroup, us per launch at 200 cameras: 16: 29.9, 8: 21.8, 4: 18.4, 2: 18.0)
+constexpr int SCALE_NB = 4;
 template <int D>
 __global__ __launch_bounds__(128) void k_scale_system(int n, int C, const double* __restrict__ S, double alpha,
                                                       const double* __restrict__ Einv, double* __restrict__ St,
