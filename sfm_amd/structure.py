@@ -117,7 +117,16 @@ def build_structure(cam_idx, pt_idx, n_cams, n_pts):
     n_blk_row = np.arange(n_cams, 0, -1, dtype=np.int64)                 # row c holds blocks (c, c..C-1)
     blk_row = np.repeat(np.arange(n_cams, dtype=np.int64), n_blk_row)
     item_row = np.repeat(blk_row, np.diff(item_ptr))
-    if os.environ.get("SFM_XCD_GROUP", "")[:1] == "c":
+    # ... unless SFM_XCD_GROUP says which, a locality statistic decides (problem.hip, k_band_stat): the mean distance from the
+    # diagonal of the non-empty off-diagonal blocks against the C / 3 of evenly spread ones; below 0.8 x: contiguous ranges
+    grp_env = os.environ.get("SFM_XCD_GROUP")
+    contig = grp_env is not None and grp_env[:1] == "c"
+    if grp_env is None and n_cams >= 16:
+        blk_col = np.concatenate([np.arange(c, n_cams, dtype=np.int64) for c in range(n_cams)])
+        work = (np.diff(item_ptr) > 0) & (blk_col > blk_row)
+        if work.any():
+            contig = bool(int((blk_col - blk_row)[work].sum()) / int(work.sum()) < 0.8 * (n_cams / 3.0))
+    if contig:
         row_cnt = np.bincount(item_row, minlength=n_cams).astype(np.int64)
         total = int(row_cnt.sum())
         mid = np.cumsum(row_cnt) - row_cnt + row_cnt // 2
