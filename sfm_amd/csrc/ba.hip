@@ -1311,7 +1311,7 @@ __global__ __launch_bounds__(128) void k_schur_assemble_scaled(int C, const int*
 // running sums; at the end the sums of equal a are added over m, the four groups and the four wavefronts in fixed order.
 template <int D, typename T, int GS>
 __global__ __launch_bounds__(256) void k_cam_reduce_chunks(const int* __restrict__ cch_beg, const int* __restrict__ cch_end,
-                                                           const int* __restrict__ cam_obs, const int* __restrict__ pt_idx,
+                                                           const int* __restrict__ cam_obs, const int* __restrict__ cam_pt,
                                                            const T* __restrict__ G, const double* __restrict__ vec,
                                                            double* __restrict__ part) {
   static_assert(D % 2 == 0 && GS % 2 == 0 && GS <= 32, "16-byte pieces of a block: one per lane of a 16-lane group");
@@ -1324,20 +1324,19 @@ __global__ __launch_bounds__(256) void k_cam_reduce_chunks(const int* __restrict
   const int m = live ? e0 / D : 0;
   double acc0 = 0.0, acc1 = 0.0;
   const int beg = cch_beg[ch], end = cch_end[ch];
-  // A trip is a chain of three dependent loads (observation id -> its point -> the point's vector, the G piece beside the point
-  // id), and with a run-time trip count each trip waited for the one before: 16 chains one after the other per 256-observation
+  // A trip was a chain of three dependent loads (observation id -> its point -> the point's vector, the G piece beside the point
+  // id; now two: the point comes from cam_pt beside the id), and with a run-time trip count each trip waited for the one before: 16 chains one after the other per 256-observation
   // chunk - the launch was as long as that (60 us at 200 cameras for 256 MB).  Four trips' loads are now issued level by level;
   // the products are still added in trip order (the same bits).
-  constexpr int UNR = 4;
+  constexpr int UNR = 4;                               // (eight: 53.8 us against 50.4)
   for (int i0 = beg + w * 4 + grp; i0 < end; i0 += 16 * UNR) {
     int k[UNR], pj[UNR];
     pair_t g[UNR];
     double vm[UNR];
 #pragma unroll
-    for (int u = 0; u < UNR; ++u) { const int i = i0 + 16 * u; k[u] = i < end ? cam_obs[i] : -1; }
+    for (int u = 0; u < UNR; ++u) { const int i = i0 + 16 * u; k[u] = i < end ? cam_obs[i] : -1; pj[u] = i < end ? cam_pt[i] : 0; }
 #pragma unroll
     for (int u = 0; u < UNR; ++u) {
-      pj[u] = k[u] >= 0 ? pt_idx[k[u]] : 0;
       g[u] = (k[u] >= 0 && live) ? *(const pair_t*)(G + (size_t)k[u] * GS + e0) : (pair_t){(T)0, (T)0};
     }
 #pragma unroll
@@ -1886,7 +1885,7 @@ extern "C" int sfm_ba_schur_build(sfm_handle h, sfm_ba_problem p, double alpha) 
     }
     if (p->has_dup && p->n_cchunks > 0)        // the chunk partials of sum_k G_k e_j by the camera-wise pass over G
       hipLaunchKernelGGL((k_cam_reduce_chunks<DD, double, GG>), dim3((unsigned)p->n_cchunks), dim3(256), 0, h->stream, p->cch_beg,
-                         p->cch_end, p->cam_obs, p->pt_idx, WS(L, G), WS(L, e), WS(L, cch_part));
+                         p->cch_end, p->cam_obs, p->cam_pt, WS(L, G), WS(L, e), WS(L, cch_part));
     // the diagonal blocks' factors for the camera CG come out of this kernel too (unsharded problems whose camera system may go to
     // the CG: a rank's S is a partial sum until the exchange)
     const bool fuse_einv = !p->sharded && p->camera_solver != SFM_CAMERA_SOLVER_CHOLESKY && (n & 1) == 0;
@@ -3134,7 +3133,7 @@ static void launch_backsub(sfm_ctx* h, sfm_ba_problem p, const Lay& L, double* w
     DISPATCH_DT(D, p->precision, {
       if (p->n_cchunks > 0)
         hipLaunchKernelGGL((k_cam_reduce_chunks<DD, double, GG>), dim3((unsigned)p->n_cchunks), dim3(256), 0, h->stream, p->cch_beg,
-                           p->cch_end, p->cam_obs, p->pt_idx, WS(L, G), WS(L, v), WS(L, cch_part));
+                           p->cch_end, p->cam_obs, p->cam_pt, WS(L, G), WS(L, v), WS(L, cch_part));
       // (+ 1 workgroup: the two sums over the point pass's per-block partials, sum ||p_p||^2 and sum ||v||^2)
       hipLaunchKernelGGL(k_cam_reduce_final<DD>, dim3(cdiv(C, 4) + 1), dim3(256), 0, h->stream, C, p->cch_ptr,
                          WS(L, cch_part), (const double*)nullptr, WS(L, red_q), WS(L, part_pt), (int)L.nblk_pt, 2, WS(L, red_q) + n);
@@ -3602,7 +3601,7 @@ struct Pcg {
       hipLaunchKernelGGL(k_track_sum, dim3(cdiv(P, 256)), dim3(256), 0, h->stream, P, p->pt_ptr, WS(L, tmp3), WS(L, v));
       if (p->n_cchunks > 0)
         hipLaunchKernelGGL((k_cam_reduce_chunks<DD, double, GG>), dim3((unsigned)p->n_cchunks), dim3(256), 0, h->stream, p->cch_beg,
-                           p->cch_end, p->cam_obs, p->pt_idx, WS(L, G), WS(L, v), WS(L, cch_part));
+                           p->cch_end, p->cam_obs, p->cam_pt, WS(L, G), WS(L, v), WS(L, cch_part));
       hipLaunchKernelGGL(k_cam_reduce_final_bv<DD>, dim3(cdiv(n, 256)), dim3(256), 0, h->stream, C, p->cch_ptr, WS(L, cch_part), WS(L, B),
                          v, WS(L, cg_Ap));
     });
@@ -3688,7 +3687,7 @@ extern "C" int sfm_ba_solve_pcg(sfm_handle h, sfm_ba_problem p, double alpha, in
     sfm_prof_begin(h, SFM_PROF_SCHUR);
     if (p->n_cchunks > 0) {
       hipLaunchKernelGGL((k_cam_reduce_chunks<DD, double, GG>), dim3((unsigned)p->n_cchunks), dim3(256), 0, h->stream, p->cch_beg,
-                         p->cch_end, p->cam_obs, p->pt_idx, WS(L, G), WS(L, e), WS(L, cch_part));
+                         p->cch_end, p->cam_obs, p->cam_pt, WS(L, G), WS(L, e), WS(L, cch_part));
       hipLaunchKernelGGL((k_cam_gg_chunks<DD, double, GG>), dim3((unsigned)p->n_cchunks), dim3(128), 0, h->stream, p->cch_beg, p->cch_end,
                          p->cam_obs, WS(L, G), WS(L, cbl_part));
     }
@@ -3722,7 +3721,7 @@ extern "C" int sfm_ba_solve_pcg(sfm_handle h, sfm_ba_problem p, double alpha, in
     DISPATCH_DT(D, p->precision, {
       if (p->n_cchunks > 0)
         hipLaunchKernelGGL((k_cam_reduce_chunks<DD, double, GG>), dim3((unsigned)p->n_cchunks), dim3(256), 0, h->stream, p->cch_beg,
-                           p->cch_end, p->cam_obs, p->pt_idx, WS(L, G), WS(L, v), WS(L, cch_part));
+                           p->cch_end, p->cam_obs, p->cam_pt, WS(L, G), WS(L, v), WS(L, cch_part));
       hipLaunchKernelGGL(k_cam_reduce_final<DD>, dim3(cdiv(C, 4)), dim3(256), 0, h->stream, C, p->cch_ptr, WS(L, cch_part),
                          (const double*)nullptr, WS(L, red_q));
     });

@@ -18,6 +18,8 @@ struct sfm_ba_prob {
   int32_t *cam_idx, *pt_idx;
   double* uv;
   int32_t *pt_ptr, *cam_ptr, *cam_obs, *blk_ptr, *pair_k, *pair_k2;
+  int32_t* cam_pt;           // [n_obs] point of cam_obs[i]: the camera-wise passes fetch it beside the observation id, not behind it
+
   int64_t n_pairs;
   int32_t *item_ptr, *item_beg, *item_end;
   int64_t n_items;

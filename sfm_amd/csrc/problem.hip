@@ -172,6 +172,10 @@ struct DevBuf {      // scoped device allocation for the construction's temporar
     if (e_ != hipSuccess) { sfm_ba_destroy_problem(p); return sfm_fail(h, SFM_ERR_HIP, #call, hipGetErrorString(e_)); } \
   } while (0)
 
+__global__ void k_cam_pt(int64_t N, const int* __restrict__ cam_obs, const int* __restrict__ pt_idx, int* __restrict__ cam_pt) {
+  const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (q < N) cam_pt[q] = pt_idx[cam_obs[q]];
+}
 __global__ void k_pair_uv(int64_t N, const int* __restrict__ cam_obs, const double2* __restrict__ uv_in, double2* __restrict__ uv_out) {
   const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (q < N) uv_out[cam_obs[q]] = uv_in[q];
@@ -179,7 +183,7 @@ __global__ void k_pair_uv(int64_t N, const int* __restrict__ cam_obs, const doub
 
 extern "C" void sfm_ba_destroy_problem(sfm_ba_problem p) {
   if (!p) return;
-  void* owned[] = {p->cam_idx, p->pt_idx, p->uv, p->pt_ptr, p->cam_ptr, p->cam_obs, p->blk_ptr, p->pair_k, p->pair_k2,
+  void* owned[] = {p->cam_idx, p->pt_idx, p->uv, p->pt_ptr, p->cam_ptr, p->cam_obs, p->cam_pt, p->blk_ptr, p->pair_k, p->pair_k2,
                    p->item_ptr, p->item_beg, p->item_end, p->xcd_ptr, p->xcd_items, p->cch_ptr, p->cch_beg, p->cch_end};
   for (void* q : owned)
     if (q) (void)hipFree(q);
@@ -268,6 +272,9 @@ extern "C" int sfm_ba_create_problem(sfm_handle h, const sfm_ba_desc* d, sfm_ba_
   PB_HIP(tmp.alloc(tmp_bytes));
   PB_HIP(rocprim::radix_sort_pairs(tmp.p, tmp_bytes, ck_in.as<unsigned>(), ck_out.as<unsigned>(), cv_in.as<unsigned>(),
                                    (unsigned*)p->cam_obs, (size_t)N, 0, (unsigned)bits_for((uint64_t)C), st));
+
+  PB_HIP(hipMalloc((void**)&p->cam_pt, N * 4));
+  hipLaunchKernelGGL(k_cam_pt, dim3(cdiv(N, 256)), dim3(256), 0, st, N, p->cam_obs, p->pt_idx, p->cam_pt);
 
   // ---- the reference's residual pairing (sfm_reconstruction.py:480-486): the q-th observation of the camera-sorted list
   // meets the q-th point-major pixel - a scatter through cam_obs (the host's np.argsort + scatter took 55 ms at 1M observations)
